@@ -1,0 +1,198 @@
+/*
+ * liogpu.h -- C ABI of the MI355X-native scan-to-map registration path.
+ *
+ * Drop-in boundary for the hot path of the reference's mapping node
+ * (src/liorf/src/mapOptmization.cpp = MO, imageProjection.cpp = IP,
+ * featureExtraction.cpp = FE, include/utility.h = UT).  The reference has no
+ * FFI/plugin interface of its own; the seam is cut where the member-state
+ * crossing is narrowest.  Plain pointers and sizes only; all
+ * device memory is owned by the opaque handle.  Nothing here throws or aborts:
+ * every entry point returns an int status (0 ok, >0 soft condition that the
+ * reference also treats as "skip", <0 hard HIP/argument error).
+ *
+ * Point clouds cross the edge in the caller's layout: `stride_bytes` between
+ * points, float x,y,z at byte offsets 0,4,8 (pcl::PointXYZI: stride 32, UT:65;
+ * a packed float[3] array: stride 12).
+ */
+#ifndef LIOGPU_H
+#define LIOGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIO_VERSION 100
+#define LIO_MAX_ITERS 32
+
+/* status codes */
+enum {
+    LIO_OK               = 0,
+    LIO_TOO_FEW_POINTS   = 1,   /* N_s <= 30, MO:1844 / MO:1862-1864: pose unchanged     */
+    LIO_TOO_FEW_CORR     = 2,   /* last iteration had < 50 correspondences, MO:1721-1724 */
+    LIO_ERR_ARG          = -1,
+    LIO_ERR_HIP          = -2,
+    LIO_ERR_CAPACITY     = -3,
+    LIO_ERR_NO_MAP       = -4,
+    LIO_ERR_NO_DEVICE    = -5
+};
+
+/* Constants of the scan-to-map loop; the caller fills them from the untouched
+ * ParamServer (UT:72-367) or keeps the defaults, which are the literals
+ * hard-coded in MO. */
+typedef struct lio_s2m_config {
+    int32_t k;               /* 5     neighbours, MO:1631 (only 5 is supported)            */
+    float   max_sq_dist;     /* 1.0   gate on the 5th neighbour, MO:1641                   */
+    double  plane_tol;       /* 0.2   MO:1662 (double literal in the reference)            */
+    double  weight;          /* 0.9   MO:1671 (double literal)                             */
+    double  min_s;           /* 0.1   MO:1679 (double literal)                             */
+    int32_t min_corr;        /* 50    MO:1722                                              */
+    int32_t max_iters;       /* 30    MO:1848 (<= LIO_MAX_ITERS)                           */
+    float   eig_thresh;      /* 100   MO:1796                                              */
+    double  conv_deg;        /* 0.05  MO:1833                                              */
+    double  conv_cm;         /* 0.05  MO:1833                                              */
+    int32_t min_scan_pts;    /* 30    MO:1844 (N_s must exceed it)                         */
+    int32_t jacobian_mode;   /* 0 = reference (MO:1764 as written), 1 = exact derivative   */
+    int32_t force_all_iters; /* 1 = ignore the convergence break MO:1857-1858              */
+    int32_t device_id;       /* HIP device ordinal                                         */
+    float   cell_size;       /* hash-grid cell edge in metres; 0 = sqrt(max_sq_dist)*1.001 */
+    int32_t max_batch;       /* capacity: scans resident per batch (>= 1)                  */
+    int32_t max_scan_pts;    /* capacity: points per scan                                  */
+    int32_t record_corr_iter;/* iteration whose correspondences are kept for
+                                lio_s2m_get_correspondences (-1 = none)                    */
+    int32_t kernel_variant;  /* 0 = auto; >0 selects an association kernel (A/B testing)   */
+    int32_t profile;         /* 1 = bracket every GN-iteration launch with HIP events      */
+} lio_s2m_config;
+
+/* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in
+ * place; MO:176-177 isDegenerate/matP; the rest is diagnostics). */
+typedef struct lio_s2m_result {
+    int32_t status;
+    int32_t iters;             /* loop bodies executed (<= max_iters)                    */
+    int32_t converged;         /* LMOptimization returned true, MO:1833-1835             */
+    int32_t is_degenerate;     /* MO:176 -> odometry_incremental covariance[0], MO:2309  */
+    int32_t n_corr_last;       /* N_c of the last executed iteration                     */
+    int32_t n_corr_iter[LIO_MAX_ITERS];
+    float   matP[36];          /* row-major, MO:177/1807                                 */
+    float   AtA[36];           /* last normal matrix, row-major, MO:1782                 */
+    float   AtB[6];            /* MO:1783                                                */
+    float   pose_iter[LIO_MAX_ITERS][6]; /* pose after each iteration                    */
+} lio_s2m_result;
+
+typedef struct lio_s2m_profile {
+    float   map_build_ms;      /* last set_map: H2D excluded, grid build kernels only     */
+    float   map_upload_ms;     /* last set_map: wall time of staging + H2D                */
+    int32_t n_launches;        /* GN-iteration launches of the last run                   */
+    float   launch_ms[LIO_MAX_ITERS]; /* device time of each (profile=1)                 */
+    int64_t point_iters;       /* scan points processed by active scans over the run      */
+    int64_t n_map;             /* resident map points                                     */
+    int64_t n_cells;           /* grid cells                                              */
+} lio_s2m_profile;
+
+typedef struct lio_s2m_handle lio_s2m_handle;
+
+int  lio_version(void);
+void lio_s2m_default_config(lio_s2m_config *cfg);
+const char *lio_last_error(void);
+
+int  lio_s2m_create(const lio_s2m_config *cfg, lio_s2m_handle **out);
+void lio_s2m_destroy(lio_s2m_handle *h);
+
+/* Replaces kdtreeSurfFromMap->setInputCloud(laserCloudSurfFromMapDS), MO:1846:
+ * copies the local map to the device as SoA and builds the hash grid. */
+int  lio_s2m_set_map(lio_s2m_handle *h, const void *pts, size_t n, size_t stride_bytes);
+
+/* Replaces the loop MO:1848-1859 for one scan (laserCloudSurfLastDS, MO:138).
+ * pose = transformTobeMapped [roll,pitch,yaw,x,y,z] (MO:171), in/out.
+ * matP / isDegenerate persist on the handle between calls like the members
+ * MO:176-177.  Synchronous. */
+int  lio_s2m_register(lio_s2m_handle *h, const void *scan, size_t n, size_t stride_bytes,
+                      float pose[6], lio_s2m_result *res);
+
+/* Batched form (BASELINE config 5): many scans against the same resident map,
+ * every scan its own pose / matP / convergence.  upload -> set_poses -> run
+ * (asynchronous on the handle's stream) -> results (synchronises). */
+int  lio_s2m_batch_upload(lio_s2m_handle *h, int32_t n_scans, const void *const *scans,
+                          const size_t *n_pts, size_t stride_bytes);
+int  lio_s2m_batch_set_poses(lio_s2m_handle *h, const float *poses /* n_scans x 6 */);
+int  lio_s2m_batch_run(lio_s2m_handle *h);
+int  lio_s2m_batch_sync(lio_s2m_handle *h);
+int  lio_s2m_batch_results(lio_s2m_handle *h, float *poses /* n_scans x 6 */,
+                           lio_s2m_result *results /* n_scans, may be NULL */);
+
+/* Persistent members MO:176-177 for batch slot `scan` (slot 0 = lio_s2m_register). */
+int  lio_s2m_set_degeneracy(lio_s2m_handle *h, int32_t scan, const float matP[36], int32_t is_degenerate);
+
+/* Association of iteration cfg.record_corr_iter for batch slot `scan`
+ * (laserCloudOriSurfFlag / coeffSelSurfVec, MO:143-145, plus the 5 neighbour
+ * indices into the caller's map order).  Arrays sized by that scan's N_s. */
+int  lio_s2m_get_correspondences(lio_s2m_handle *h, int32_t scan, uint8_t *flag,
+                                 float *coeff4, int32_t *nn_idx5);
+
+int  lio_s2m_get_profile(lio_s2m_handle *h, lio_s2m_profile *out);
+
+/* Multi-GPU hooks (one process per GPU; the caller owns the collective).
+ * The map given to set_map is this rank's shard INCLUDING a halo of one cell;
+ * lio_s2m_set_shard restricts which transformed scan points this rank owns
+ * (owner-computes): cells whose index along `axis` lies in [lo, hi) of the
+ * GLOBAL grid described by origin/dims.  iter_partial leaves per-scan sums
+ * (n_scans x 32 doubles: 21 upper JtJ, 6 Jtr, N_c, pad) in a device buffer;
+ * the caller all-reduces it and iter_apply solves + updates every scan. */
+int  lio_s2m_set_stream(lio_s2m_handle *h, void *hip_stream);
+int  lio_s2m_set_global_grid(lio_s2m_handle *h, const float origin[3], const int32_t dims[3]);
+int  lio_s2m_set_shard(lio_s2m_handle *h, int32_t axis, int32_t lo, int32_t hi);
+int  lio_s2m_batch_begin(lio_s2m_handle *h);
+int  lio_s2m_batch_iter_partial(lio_s2m_handle *h, double *d_sums /* device, n_scans x 32 */);
+int  lio_s2m_batch_iter_apply(lio_s2m_handle *h, const double *d_sums);
+int  lio_s2m_batch_n_active(lio_s2m_handle *h, int32_t *n_active);
+
+/* transformUpdate + constraintTransformation, MO:1867-1907 (host, fp64 slerp). */
+void lio_transform_update(float pose[6], int32_t imu_available, int32_t imu_type,
+                          float imu_roll_init, float imu_pitch_init, float imu_rpy_weight,
+                          float rotation_tollerance, float z_tollerance);
+
+/* ------------------------------------------------------------------ deskew */
+/* Filters of projectPointCloud IP:577-615, keys UT:275-285. */
+typedef struct lio_deskew_config {
+    int32_t N_SCAN;
+    int32_t downsampleRate;
+    int32_t point_filter_num;
+    float   lidarMinFront, lidarMinBack, lidarMinLeft, lidarMinRight;
+    float   lidarMaxRange;
+    float   lidarMaxIntensity;
+    int32_t deskew_flag;      /* -1 = cloud has no per-point time field, IP:547 */
+    int32_t device_id;
+} lio_deskew_config;
+
+void lio_deskew_default_config(lio_deskew_config *cfg);
+
+/* imuDeskewInfo, IP:359-418 (host, fp64): integrates the gyro over the sweep.
+ * Tables have room for 2000 entries (queueLength, IP:62).  Returns
+ * imuPointerCur (> 0 <=> cloudInfo.imuAvailable). */
+int  lio_imu_deskew_info(const double *stamp, const double *gyro_x, const double *gyro_y,
+                         const double *gyro_z, int32_t n_imu,
+                         double time_scan_cur, double time_scan_end,
+                         double *imuTime, double *imuRotX, double *imuRotY, double *imuRotZ);
+
+/* projectPointCloud + deskewPoint, IP:545-615, on the device.
+ * pts: PointXYZIRT records (IP:4-15): float x,y,z @0,4,8; float intensity @16;
+ * uint16 ring @20; float time @24; stride 32.  out: pcl::PointXYZI-compatible
+ * records (x,y,z @0,4,8, intensity @16) with `out_stride_bytes` (>= 20),
+ * input order preserved.  Returns status; *n_out = survivors. */
+int  lio_deskew(const lio_deskew_config *cfg, const void *pts, size_t n, size_t stride_bytes,
+                double time_scan_cur,
+                const double *imuTime, const double *imuRotX, const double *imuRotY,
+                const double *imuRotZ, int32_t imuPointerCur,
+                void *out, size_t out_stride_bytes, size_t *n_out);
+
+/* calculateSmoothness, FE:81-101: curvature[i] for i in [5, n-5), also zeroes
+ * neighbor_picked / label there (either may be NULL).  Host pointers. */
+int  lio_curvature(int32_t device_id, const float *range, size_t n, float *curvature,
+                   int32_t *neighbor_picked, int32_t *label);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIOGPU_H */

@@ -1,0 +1,394 @@
+// lio_device_math.h -- per-thread fp32 arithmetic of the scan-to-map path for
+// gfx950.  Compiled with -ffp-contract=off: every expression below keeps the
+// reference's operator order so that results are bit-identical to a CPU build
+// of the reference without FMA contraction (src/liorf/CMakeLists.txt:7).
+//
+//   MO = /root/reference/src/liorf/src/mapOptmization.cpp
+//
+// Everything here lives in registers: loops have compile-time trip counts and
+// are fully unrolled, pivot swaps are selects, so no scratch memory is touched.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#define LIO_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- plane fit
+// matA0.colPivHouseholderQr().solve(matB0) with matB0 = -1, MO:1633-1648
+// (Eigen 3.3 ColPivHouseholderQR: pivot on the largest updated column norm,
+// LAPACK-style norm downdating, makeHouseholderInPlace, column-oriented
+// back-substitution over nonzeroPivots()).  a[r][c]: 5 neighbours x (x,y,z).
+LIO_DEV void lio_plane_qr5x3(float a[5][3], float x[3])
+{
+    float hc[3], direct[3], upd[3];
+    int trans[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) s += a[i][k] * a[i][k];
+        direct[k] = sqrtf(s);
+        upd[k] = direct[k];
+    }
+    float maxn = upd[0];
+    if (upd[1] > maxn) maxn = upd[1];
+    if (upd[2] > maxn) maxn = upd[2];
+    const float th = maxn * FLT_EPSILON;
+    const float threshold_helper = (th * th) / 5.0f;
+    const float downdate_thr = sqrtf(FLT_EPSILON);
+    int nz = 3;
+
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int big = k;
+        float bigv = upd[k];
+#pragma unroll
+        for (int j = k + 1; j < 3; ++j)
+            if (upd[j] > bigv) { bigv = upd[j]; big = j; }
+        const float big_sq = bigv * bigv;
+        if (nz == 3 && big_sq < threshold_helper * (float)(5 - k)) nz = k;
+        trans[k] = big;
+#pragma unroll
+        for (int j = k + 1; j < 3; ++j) {
+            const bool sw = (big == j);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const float u = a[i][k], v = a[i][j];
+                a[i][k] = sw ? v : u;
+                a[i][j] = sw ? u : v;
+            }
+            const float u0 = upd[k], u1 = upd[j], d0 = direct[k], d1 = direct[j];
+            upd[k] = sw ? u1 : u0;       upd[j] = sw ? u0 : u1;
+            direct[k] = sw ? d1 : d0;    direct[j] = sw ? d0 : d1;
+        }
+        float tail_sq = 0.0f;
+#pragma unroll
+        for (int i = k + 1; i < 5; ++i) tail_sq += a[i][k] * a[i][k];
+        const float c0 = a[k][k];
+        float beta, tau;
+        if (tail_sq <= FLT_MIN) {
+            tau = 0.0f; beta = c0;
+#pragma unroll
+            for (int i = k + 1; i < 5; ++i) a[i][k] = 0.0f;
+        } else {
+            beta = sqrtf(c0 * c0 + tail_sq);
+            if (c0 >= 0.0f) beta = -beta;
+            const float den = c0 - beta;
+#pragma unroll
+            for (int i = k + 1; i < 5; ++i) a[i][k] = a[i][k] / den;
+            tau = (beta - c0) / beta;
+        }
+        hc[k] = tau;
+        a[k][k] = beta;
+        if (tau != 0.0f) {
+#pragma unroll
+            for (int j = k + 1; j < 3; ++j) {
+                float tmp = 0.0f;
+#pragma unroll
+                for (int i = k + 1; i < 5; ++i) tmp += a[i][k] * a[i][j];
+                tmp += a[k][j];
+                a[k][j] -= tau * tmp;
+#pragma unroll
+                for (int i = k + 1; i < 5; ++i) a[i][j] -= (tau * a[i][k]) * tmp;
+            }
+        }
+#pragma unroll
+        for (int j = k + 1; j < 3; ++j) {
+            if (upd[j] != 0.0f) {
+                float temp = fabsf(a[k][j]) / upd[j];
+                temp = (1.0f + temp) * (1.0f - temp);
+                temp = temp < 0.0f ? 0.0f : temp;
+                const float ratio = upd[j] / direct[j];
+                const float temp2 = temp * (ratio * ratio);
+                if (temp2 <= downdate_thr) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int i = k + 1; i < 5; ++i) s += a[i][j] * a[i][j];
+                    direct[j] = sqrtf(s);
+                    upd[j] = direct[j];
+                } else {
+                    upd[j] *= sqrtf(temp);
+                }
+            }
+        }
+    }
+    // permutation from the transpositions: perm = identity; swap(perm[k], perm[trans[k]])
+    int p0 = 0, p1 = 1, p2 = 2;
+    {   // k = 0
+        const int t = trans[0];
+        const int q0 = p0, q1 = p1, q2 = p2;
+        p0 = (t == 1) ? q1 : (t == 2) ? q2 : q0;
+        p1 = (t == 1) ? q0 : q1;
+        p2 = (t == 2) ? q0 : q2;
+    }
+    {   // k = 1
+        const int t = trans[1];
+        const int q1 = p1, q2 = p2;
+        p1 = (t == 2) ? q2 : q1;
+        p2 = (t == 2) ? q1 : q2;
+    }
+    // k = 2: trans[2] == 2 always
+
+    // c = Q^T b with b = -1 (matB0.fill(-1), MO:1638), first nz reflectors
+    float c[5] = { -1.0f, -1.0f, -1.0f, -1.0f, -1.0f };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < nz) {
+            const float tau = hc[k];
+            if (tau != 0.0f) {
+                float tmp = 0.0f;
+#pragma unroll
+                for (int i = k + 1; i < 5; ++i) tmp += a[i][k] * c[i];
+                tmp += c[k];
+                c[k] -= tau * tmp;
+#pragma unroll
+                for (int i = k + 1; i < 5; ++i) c[i] -= (tau * a[i][k]) * tmp;
+            }
+        }
+    }
+    // upper-triangular solve on the leading nz x nz block, column oriented
+#pragma unroll
+    for (int i = 2; i >= 0; --i) {
+        if (i < nz) {
+            if (c[i] != 0.0f) {
+                c[i] /= a[i][i];
+#pragma unroll
+                for (int r = 0; r < i; ++r) c[r] -= c[i] * a[r][i];
+            }
+        }
+    }
+    const float v0 = (0 < nz) ? c[0] : 0.0f;
+    const float v1 = (1 < nz) ? c[1] : 0.0f;
+    const float v2 = (2 < nz) ? c[2] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        x[j] = (p0 == j) ? v0 : (p1 == j) ? v1 : (p2 == j) ? v2 : 0.0f;
+}
+
+// --------------------------------------------------------------- Jacobian
+// One row of matA and matB, MO:1760-1778.  tr = {srx,crx,sry,cry,srz,crz} with
+// the reference's names: rx <- yaw, ry <- pitch, rz <- roll (MO:1714-1719).
+// jac_exact swaps the MO:1764 term for the analytic derivative.
+LIO_DEV void lio_jacobian_row(const float tr[6], float px, float py, float pz,
+                              float cx, float cy, float cz, float cw, int jac_exact,
+                              float row[6], float &rhs)
+{
+    const float srx = tr[0], crx = tr[1], sry = tr[2], cry = tr[3], srz = tr[4], crz = tr[5];
+    const float arx = (-srx * cry * px - (srx * sry * srz + crx * crz) * py + (crx * srz - srx * sry * crz) * pz) * cx
+                    + (crx * cry * px - (srx * crz - crx * sry * srz) * py + (crx * sry * crz + srx * srz) * pz) * cy;
+    const float mid = jac_exact ? (srx * cry * srz * py) : (srx * sry * srz * py);
+    const float ary = (-crx * sry * px + crx * cry * srz * py + crx * cry * crz * pz) * cx
+                    + (-srx * sry * px + mid + srx * cry * crz * pz) * cy
+                    + (-cry * px - sry * srz * py - sry * crz * pz) * cz;
+    const float arz = ((crx * sry * crz + srx * srz) * py + (srx * crz - crx * sry * srz) * pz) * cx
+                    + ((-crx * srz + srx * sry * crz) * py + (-srx * sry * srz - crx * crz) * pz) * cy
+                    + (cry * crz * py - cry * srz * pz) * cz;
+    row[0] = arz; row[1] = ary; row[2] = arx;
+    row[3] = cx;  row[4] = cy;  row[5] = cz;
+    rhs = -cw;
+}
+
+// ------------------------------------------------- 6x6 normal-equation step
+// Executed by ONE lane per scan per iteration (the serial tail of the GN
+// step).  All working storage is a caller-provided LDS workspace so that the
+// association kernel needs no scratch memory.
+struct LioSolveWs {
+    float A[36];      // destroyed by the factorisations
+    float B[36];      // inverse / scratch
+    float V[36];
+    float V2[36];
+    float AtA[36];
+    float AtB[6], X[6], X2[6], W[6], vl[6], hf[6];
+    int   indR[6], indC[6];
+};
+
+// cv::solve(AtA, AtB, X, DECOMP_QR), MO:1784 (OpenCV hal::QR32f: Householder
+// with unit-norm reflectors, then back substitution; singular -> X = 0).
+// A (6x6 row-major) is destroyed, b is replaced by the solution.
+__device__ static int lio_solve6_qr(float* A, float* b, float* vl, float* hf)
+{
+    const float eps = FLT_EPSILON * 10;
+    for (int l = 0; l < 6; ++l) {
+        const int vs = 6 - l;
+        float vnorm = 0.0f;
+        for (int i = 0; i < vs; ++i) { vl[i] = A[(l + i) * 6 + l]; vnorm += vl[i] * vl[i]; }
+        const float tmpv = vl[0];
+        const float sg = vl[0] >= 0.0f ? 1.0f : -1.0f;
+        vl[0] = vl[0] + sg * sqrtf(vnorm);
+        vnorm = sqrtf(vnorm + vl[0] * vl[0] - tmpv * tmpv);
+        for (int i = 0; i < vs; ++i) vl[i] /= vnorm;
+        for (int j = l; j < 6; ++j) {
+            float va = 0.0f;
+            for (int i = l; i < 6; ++i) va += vl[i - l] * A[i * 6 + j];
+            for (int i = l; i < 6; ++i) A[i * 6 + j] -= 2 * vl[i - l] * va;
+        }
+        hf[l] = vl[0] * vl[0];
+        for (int i = 1; i < vs; ++i) A[(l + i) * 6 + l] = vl[i] / vl[0];
+    }
+    for (int l = 0; l < 6; ++l) {
+        vl[0] = 1.0f;
+        for (int j = 1; j < 6 - l; ++j) vl[j] = A[(j + l) * 6 + l];
+        float vb = 0.0f;
+        for (int i = l; i < 6; ++i) vb += vl[i - l] * b[i];
+        for (int i = l; i < 6; ++i) b[i] -= 2 * vl[i - l] * vb * hf[l];
+    }
+    for (int i = 5; i >= 0; --i) {
+        for (int j = 5; j > i; --j) b[i] -= b[j] * A[i * 6 + j];
+        if (fabsf(A[i * 6 + i]) < eps) { for (int p = 0; p < 6; ++p) b[p] = 0.0f; return 0; }
+        b[i] /= A[i * 6 + i];
+    }
+    return 1;
+}
+
+__device__ static float lio_cv_hypot(float a, float b)
+{
+    a = fabsf(a); b = fabsf(b);
+    if (a > b) { b /= a; return a * sqrtf(1 + b * b); }
+    if (b > 0) { a /= b; return b * sqrtf(1 + a * a); }
+    return 0.0f;
+}
+
+// cv::eigen(matAtA, matE, matV), MO:1792 (OpenCV JacobiImpl_: largest
+// off-diagonal pivot tracked per row/column; eigenvalues sorted descending,
+// eigenvectors as rows).  A is destroyed.
+__device__ static void lio_eigen6_sym(float* A, float* W, float* V, int* indR, int* indC)
+{
+    const float eps = FLT_EPSILON;
+    int i, j, k, m;
+    float mv;
+    for (i = 0; i < 6; ++i) for (j = 0; j < 6; ++j) V[i * 6 + j] = (i == j) ? 1.0f : 0.0f;
+    for (k = 0; k < 6; ++k) {
+        W[k] = A[k * 6 + k];
+        if (k < 5) {
+            for (m = k + 1, mv = fabsf(A[k * 6 + m]), i = k + 2; i < 6; ++i) {
+                const float val = fabsf(A[k * 6 + i]);
+                if (mv < val) { mv = val; m = i; }
+            }
+            indR[k] = m;
+        }
+        if (k > 0) {
+            for (m = 0, mv = fabsf(A[k]), i = 1; i < k; ++i) {
+                const float val = fabsf(A[i * 6 + k]);
+                if (mv < val) { mv = val; m = i; }
+            }
+            indC[k] = m;
+        }
+    }
+    for (int iters = 0; iters < 6 * 6 * 30; ++iters) {
+        for (k = 0, mv = fabsf(A[indR[0]]), i = 1; i < 5; ++i) {
+            const float val = fabsf(A[i * 6 + indR[i]]);
+            if (mv < val) { mv = val; k = i; }
+        }
+        int l = indR[k];
+        for (i = 1; i < 6; ++i) {
+            const float val = fabsf(A[indC[i] * 6 + i]);
+            if (mv < val) { mv = val; k = indC[i]; l = i; }
+        }
+        const float p = A[k * 6 + l];
+        if (fabsf(p) <= eps) break;
+        const float y = (float)((W[l] - W[k]) * 0.5);
+        float t = fabsf(y) + lio_cv_hypot(p, y);
+        float s = lio_cv_hypot(p, t);
+        const float c = t / s;
+        s = p / s; t = (p / t) * p;
+        if (y < 0) { s = -s; t = -t; }
+        A[k * 6 + l] = 0;
+        W[k] -= t;
+        W[l] += t;
+        float a0, b0;
+#define LIO_ROT(v0, v1) do { a0 = (v0); b0 = (v1); (v0) = a0 * c - b0 * s; (v1) = a0 * s + b0 * c; } while (0)
+        for (i = 0; i < k; ++i)     LIO_ROT(A[i * 6 + k], A[i * 6 + l]);
+        for (i = k + 1; i < l; ++i) LIO_ROT(A[k * 6 + i], A[i * 6 + l]);
+        for (i = l + 1; i < 6; ++i) LIO_ROT(A[k * 6 + i], A[l * 6 + i]);
+        for (i = 0; i < 6; ++i)     LIO_ROT(V[k * 6 + i], V[l * 6 + i]);
+#undef LIO_ROT
+        for (j = 0; j < 2; ++j) {
+            const int idx = j == 0 ? k : l;
+            if (idx < 5) {
+                for (m = idx + 1, mv = fabsf(A[idx * 6 + m]), i = idx + 2; i < 6; ++i) {
+                    const float val = fabsf(A[idx * 6 + i]);
+                    if (mv < val) { mv = val; m = i; }
+                }
+                indR[idx] = m;
+            }
+            if (idx > 0) {
+                for (m = 0, mv = fabsf(A[idx]), i = 1; i < idx; ++i) {
+                    const float val = fabsf(A[i * 6 + idx]);
+                    if (mv < val) { mv = val; m = i; }
+                }
+                indC[idx] = m;
+            }
+        }
+    }
+    for (k = 0; k < 5; ++k) {
+        m = k;
+        for (i = k + 1; i < 6; ++i) if (W[m] < W[i]) m = i;
+        if (k != m) {
+            float t = W[m]; W[m] = W[k]; W[k] = t;
+            for (i = 0; i < 6; ++i) { t = V[m * 6 + i]; V[m * 6 + i] = V[k * 6 + i]; V[k * 6 + i] = t; }
+        }
+    }
+}
+
+// matV.inv(), MO:1807 (OpenCV hal::LU32f on [A | I], partial pivoting;
+// singular -> zero matrix).  A is destroyed, B receives the inverse.
+__device__ static int lio_inv6_lu(float* A, float* B)
+{
+    const float eps = FLT_EPSILON * 10;
+    int i, j, k;
+    for (i = 0; i < 6; ++i) for (j = 0; j < 6; ++j) B[i * 6 + j] = (i == j) ? 1.0f : 0.0f;
+    for (i = 0; i < 6; ++i) {
+        k = i;
+        for (j = i + 1; j < 6; ++j) if (fabsf(A[j * 6 + i]) > fabsf(A[k * 6 + i])) k = j;
+        if (fabsf(A[k * 6 + i]) < eps) { for (j = 0; j < 36; ++j) B[j] = 0.0f; return 0; }
+        if (k != i) {
+            for (j = i; j < 6; ++j) { const float t = A[i * 6 + j]; A[i * 6 + j] = A[k * 6 + j]; A[k * 6 + j] = t; }
+            for (j = 0; j < 6; ++j) { const float t = B[i * 6 + j]; B[i * 6 + j] = B[k * 6 + j]; B[k * 6 + j] = t; }
+        }
+        const float d = -1 / A[i * 6 + i];
+        for (j = i + 1; j < 6; ++j) {
+            const float alpha = A[j * 6 + i] * d;
+            for (k = i + 1; k < 6; ++k) A[j * 6 + k] += alpha * A[i * 6 + k];
+            for (k = 0; k < 6; ++k) B[j * 6 + k] += alpha * B[i * 6 + k];
+        }
+    }
+    for (i = 5; i >= 0; --i)
+        for (j = 0; j < 6; ++j) {
+            float s = B[i * 6 + j];
+            for (k = i + 1; k < 6; ++k) s -= A[i * 6 + k] * B[k * 6 + j];
+            B[i * 6 + j] = s / A[i * 6 + i];
+        }
+    return 1;
+}
+
+// CV_32F matrix product (double accumulation over k, rounded once).
+__device__ static void lio_gemm32f(const float* A, const float* B, float* C, int m, int k, int n)
+{
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int p = 0; p < k; ++p) s += (double)A[i * k + p] * (double)B[p * n + j];
+            C[i * n + j] = (float)s;
+        }
+}
+
+// fp32 sine/cosine defined as the fp64 function rounded once (see DESIGN.md,
+// "trig"): the reference's sin(float)/cos(float) (MO:1714-1719, PCL
+// getTransformation) up to the last-bit freedom of the platform libm.
+__device__ static float lio_sinf(float x) { return (float)sin((double)x); }
+__device__ static float lio_cosf(float x) { return (float)cos((double)x); }
+
+// pcl::getTransformation(x,y,z,roll,pitch,yaw) as used by trans2Affine3f, MO:887-890.
+__device__ static void lio_pose_to_transform(const float pose[6], float T[12], float trig[6])
+{
+    const float A = lio_cosf(pose[2]), B = lio_sinf(pose[2]);   // yaw
+    const float C = lio_cosf(pose[1]), D = lio_sinf(pose[1]);   // pitch
+    const float E = lio_cosf(pose[0]), F = lio_sinf(pose[0]);   // roll
+    const float DE = D * E, DF = D * F;
+    T[0] = A * C;  T[1] = A * DF - B * E;  T[2]  = B * F + A * DE;  T[3]  = pose[3];
+    T[4] = B * C;  T[5] = A * E + B * DF;  T[6]  = B * DE - A * F;  T[7]  = pose[4];
+    T[8] = -D;     T[9] = C * F;           T[10] = C * E;           T[11] = pose[5];
+    // LMOptimization's names (MO:1714-1719): srx=sin(yaw) ... crz=cos(roll)
+    trig[0] = B; trig[1] = A; trig[2] = D; trig[3] = C; trig[4] = F; trig[5] = E;
+}

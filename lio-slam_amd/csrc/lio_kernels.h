@@ -1,0 +1,38 @@
+// lio_kernels.h -- launch interface between the C-ABI implementation and the
+// gfx950 kernels (lio_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "lio_types.h"
+
+struct LioIterParams {
+    LioGrid grid;
+    LioShard shard;
+    LioConsts c;
+    const float4* map_sorted;      // cell-sorted (x,y,z,bits(orig index))
+    const float4* map_xyz4;        // caller order (x,y,z,0) -- the 5 winners are re-read here
+    const int* cell_start;         // n_cells + 1
+    const float* sx;               // batch scan SoA (all scans concatenated)
+    const float* sy;
+    const float* sz;
+    LioScanState* state;
+    const LioBlockDesc* blocks;
+    double* partials;              // [scan][max_blk][LIO_SUMS]
+    unsigned* arrive;              // [scan] arrival counters
+    int max_blk;
+    double* sums_out;              // sharded mode: [scan][LIO_SUMS]; nullptr = solve in place
+    unsigned char* rec_flag;       // optional correspondence record (iteration c.record_iter)
+    float* rec_coeff;
+    int* rec_nn;
+};
+
+void lio_launch_aos_to_soa(const void* src, size_t stride, int n, float* x, float* y, float* z,
+                           float4* xyz4, hipStream_t s);
+void lio_launch_map_bbox(const float* x, const float* y, const float* z, int n, unsigned* bbox, hipStream_t s);
+void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, const float* z, int n,
+                          int* cell_of, int* cell_count, int* cell_start, int* tile_sums,
+                          float4* sorted, hipStream_t s);
+int  lio_scan_tiles(int n_cells);
+void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c, hipStream_t s);
+void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, hipStream_t s);
+void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c, hipStream_t s);
+void lio_launch_count_active(const LioScanState* st, int n_scans, int* out, hipStream_t s);

@@ -1,0 +1,582 @@
+// lio_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the scan-to-map
+// registration path.  MO = /root/reference/src/liorf/src/mapOptmization.cpp.
+//
+//   map build : k_map_bbox, k_map_cell_count, k_scan_*, k_map_scatter
+//               (replaces the kd-tree build at MO:1846)
+//   GN iterate: k_s2m_iterate  = surfOptimization MO:1618-1687
+//                              + combineOptimizationCoeffs MO:1689-1700 (as a sum)
+//                              + LMOptimization MO:1702-1837 (last workgroup of a scan)
+//
+// Compile with -ffp-contract=off (bit parity with the reference's arithmetic).
+#include <hip/hip_runtime.h>
+#include "lio_types.h"
+#include "lio_device_math.h"
+#include "lio_kernels.h"
+
+// ------------------------------------------------------------------ helpers
+LIO_DEV int lio_cell_coord(float v, float origin, float inv_cell, int n)
+{
+    // monotone in v; clamped to [-2, n+1] so that NaN / far-away queries land
+    // outside every 27-neighbourhood instead of overflowing the int conversion
+    float c = floorf((v - origin) * inv_cell);
+    c = fminf(fmaxf(c, -2.0f), (float)(n + 1));
+    return (int)c;
+}
+
+LIO_DEV unsigned lio_f2ord(float f)   // order-preserving float -> uint
+{
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ------------------------------------------------------------- AoS -> SoA
+// pcl::PointXYZI records (x,y,z at byte 0,4,8; stride given) -> x[],y[],z[]
+__global__ void k_aos_to_soa(const unsigned char* __restrict__ src, size_t stride, int n,
+                             float* __restrict__ x, float* __restrict__ y, float* __restrict__ z,
+                             float4* __restrict__ xyz4 /* optional */)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = reinterpret_cast<const float*>(src + (size_t)i * stride);
+    const float a = p[0], b = p[1], c = p[2];
+    x[i] = a; y[i] = b; z[i] = c;
+    if (xyz4) xyz4[i] = make_float4(a, b, c, 0.0f);
+}
+
+// ---------------------------------------------------------------- map build
+// bbox[0..2] = min (ordered uint), bbox[3..5] = max
+__global__ void k_map_bbox(const float* __restrict__ x, const float* __restrict__ y,
+                           const float* __restrict__ z, int n, unsigned* __restrict__ bbox)
+{
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float v[3] = { x[i], y[i], z[i] };
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            // NaN / inf coordinates are ignored for the box (they can never be a
+            // neighbour within 1 m of anything)
+            if (fabsf(v[a]) <= 3.0e38f) { mn[a] = fminf(mn[a], v[a]); mx[a] = fmaxf(mx[a], v[a]); }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&bbox[a], lio_f2ord(mn[a]));
+            atomicMax(&bbox[3 + a], lio_f2ord(mx[a]));
+        }
+    }
+}
+
+LIO_DEV int lio_map_cell(const LioGrid& g, float px, float py, float pz)
+{
+    const int cx = lio_cell_coord(px, g.ox, g.inv_cell, g.nx);
+    const int cy = lio_cell_coord(py, g.oy, g.inv_cell, g.ny);
+    const int cz = lio_cell_coord(pz, g.oz, g.inv_cell, g.nz);
+    if (cx < 0 || cx >= g.nx || cy < 0 || cy >= g.ny || cz < 0 || cz >= g.nz) return -1;
+    return (cz * g.ny + cy) * g.nx + cx;
+}
+
+__global__ void k_map_cell_count(LioGrid g, const float* __restrict__ x, const float* __restrict__ y,
+                                 const float* __restrict__ z, int n,
+                                 int* __restrict__ cell_of, int* __restrict__ cell_count)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = lio_map_cell(g, x[i], y[i], z[i]);
+    cell_of[i] = c;
+    if (c >= 0) atomicAdd(&cell_count[c], 1);
+}
+
+// exclusive scan of cell_count[0..n) -> cell_start[0..n], three phases
+#define LIO_SCAN_ITEMS 16
+#define LIO_SCAN_TILE (256 * LIO_SCAN_ITEMS)
+
+LIO_DEV int lio_block_exclusive_scan(int v, int* total, int* s_wave /* >= 4 ints */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int s = s_wave[w]; if (w < wave) wave_off += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return wave_off + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const int* __restrict__ in, int n, int* __restrict__ tile_sums)
+{
+    __shared__ int s_wave[4];
+    const int base = blockIdx.x * LIO_SCAN_TILE + threadIdx.x * LIO_SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < LIO_SCAN_ITEMS; ++k) if (base + k < n) s += in[base + k];
+    int tot;
+    lio_block_exclusive_scan(s, &tot, s_wave);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_scan_tile_offsets(int* __restrict__ tile_sums, int n_tiles)
+{
+    __shared__ int s_wave[4];
+    int carry = 0;
+    for (int b = 0; b < n_tiles; b += 256) {
+        const int i = b + threadIdx.x;
+        const int v = i < n_tiles ? tile_sums[i] : 0;
+        int tot;
+        const int ex = lio_block_exclusive_scan(v, &tot, s_wave);
+        if (i < n_tiles) tile_sums[i] = carry + ex;
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const int* __restrict__ in, int n,
+                                                    const int* __restrict__ tile_offsets,
+                                                    int* __restrict__ out /* n+1 */)
+{
+    __shared__ int s_wave[4];
+    const int base = blockIdx.x * LIO_SCAN_TILE + threadIdx.x * LIO_SCAN_ITEMS;
+    int v[LIO_SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < LIO_SCAN_ITEMS; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    int tot;
+    int run = tile_offsets[blockIdx.x] + lio_block_exclusive_scan(s, &tot, s_wave);
+#pragma unroll
+    for (int k = 0; k < LIO_SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+        if (base + k == n - 1) out[n] = run;
+    }
+}
+
+// sorted[cell_start[c] + slot] = (x, y, z, bits(original index))
+__global__ void k_map_scatter(const float* __restrict__ x, const float* __restrict__ y,
+                              const float* __restrict__ z, int n,
+                              const int* __restrict__ cell_of, const int* __restrict__ cell_start,
+                              int* __restrict__ cell_fill, float4* __restrict__ sorted)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell_of[i];
+    if (c < 0) return;
+    const int slot = atomicAdd(&cell_fill[c], 1);
+    sorted[cell_start[c] + slot] = make_float4(x[i], y[i], z[i], __int_as_float(i));
+}
+
+// -------------------------------------------------------------- GN iterate
+// top-5 keys: (bits(d2) << 32) | original index -- d2 >= 0, so the unsigned
+// 64-bit order is the lexicographic (d2, index) order of the exact k-NN
+// (pcl::KdTreeFLANN::nearestKSearch MO:1631: ascending squared distance; ties
+// by the smaller map index).
+LIO_DEV void lio_cswap(unsigned long long& a, unsigned long long& b)
+{
+    const unsigned long long lo = a < b ? a : b;
+    const unsigned long long hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+
+struct LioTop5 { unsigned long long k0, k1, k2, k3, k4; };
+
+LIO_DEV void lio_top5_insert(LioTop5& t, unsigned long long key)
+{
+    if (key < t.k4) {
+        t.k4 = key;
+        lio_cswap(t.k3, t.k4);
+        lio_cswap(t.k2, t.k3);
+        lio_cswap(t.k1, t.k2);
+        lio_cswap(t.k0, t.k1);
+    }
+}
+
+// FLANN L2_Simple: ((dx*dx) + dy*dy) + dz*dz, accumulated from 0
+LIO_DEV float lio_sqdist(float ax, float ay, float az, float bx, float by, float bz)
+{
+    float r = 0.0f, d;
+    d = ax - bx; r += d * d;
+    d = ay - by; r += d * d;
+    d = az - bz; r += d * d;
+    return r;
+}
+
+// Wave-wide sum with a fixed butterfly tree (deterministic).
+LIO_DEV double lio_wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// The serial Gauss-Newton step of one scan: LMOptimization MO:1702-1837 from
+// the reduced sums onward, plus the loop control of scan2MapOptimization
+// MO:1848-1859.  One lane; `ws` is LDS (or any) working storage.
+__device__ static void lio_gn_step(LioScanState* st, const double* sums, const LioConsts& c, LioSolveWs* ws)
+{
+    const int it = st->iter;
+    const int nc = (int)sums[LIO_SUM_NC];
+    float pose[6];
+    for (int k = 0; k < 6; ++k) pose[k] = st->pose[k];
+    bool conv = false;
+    st->n_corr_last = nc;
+    if (it < 32) st->n_corr_iter[it] = nc;
+
+    if (nc >= c.min_corr) {                                    // MO:1721-1724
+        int p = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) {
+                const float v = (float)sums[p++];
+                ws->AtA[a * 6 + b] = v; ws->AtA[b * 6 + a] = v;
+            }
+        for (int a = 0; a < 6; ++a) ws->AtB[a] = (float)sums[21 + a];
+        for (int k = 0; k < 36; ++k) { st->AtA[k] = ws->AtA[k]; ws->A[k] = ws->AtA[k]; }
+        for (int k = 0; k < 6; ++k) { st->AtB[k] = ws->AtB[k]; ws->X[k] = ws->AtB[k]; }
+
+        lio_solve6_qr(ws->A, ws->X, ws->vl, ws->hf);           // MO:1784
+
+        if (it == 0) {                                         // MO:1786-1808
+            for (int k = 0; k < 36; ++k) ws->A[k] = ws->AtA[k];
+            lio_eigen6_sym(ws->A, ws->W, ws->V, ws->indR, ws->indC);
+            for (int k = 0; k < 36; ++k) ws->V2[k] = ws->V[k];
+            int deg = 0;
+            for (int i = 5; i >= 0; --i) {
+                if (ws->W[i] < c.eig_thresh) {
+                    for (int j = 0; j < 6; ++j) ws->V2[i * 6 + j] = 0;
+                    deg = 1;
+                } else {
+                    break;
+                }
+            }
+            for (int k = 0; k < 36; ++k) ws->A[k] = ws->V[k];
+            lio_inv6_lu(ws->A, ws->B);
+            lio_gemm32f(ws->B, ws->V2, st->matP, 6, 6, 6);     // MO:1807
+            st->is_degenerate = deg;
+        }
+        if (st->is_degenerate) {                               // MO:1810-1815
+            for (int k = 0; k < 6; ++k) ws->X2[k] = ws->X[k];
+            lio_gemm32f(st->matP, ws->X2, ws->X, 6, 6, 1);
+        }
+        for (int k = 0; k < 6; ++k) pose[k] += ws->X[k];       // MO:1817-1822
+
+        // MO:1824-1831: rad2deg in float, squares/sqrt in double, stored as float
+        const double r0 = (double)(ws->X[0] * 57.29578f), r1 = (double)(ws->X[1] * 57.29578f), r2 = (double)(ws->X[2] * 57.29578f);
+        const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+        const double t0 = (double)(ws->X[3] * 100), t1 = (double)(ws->X[4] * 100), t2 = (double)(ws->X[5] * 100);
+        const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+        conv = ((double)deltaR < c.conv_deg) && ((double)deltaT < c.conv_cm);   // MO:1833
+    }
+
+    for (int k = 0; k < 6; ++k) st->pose[k] = pose[k];
+    if (it < 32) for (int k = 0; k < 6; ++k) st->pose_iter[it][k] = pose[k];
+    int iters = it + 1;
+    int done = 0;
+    if (conv) { st->converged = 1; if (!c.force_all) done = 1; }   // MO:1857-1858
+    if (iters >= c.max_iters) done = 1;                            // MO:1848
+    if (nc < c.min_corr && !done) {
+        // LMOptimization returned false WITHOUT touching the pose (MO:1721-1724):
+        // every remaining iteration would redo identical work.  Fast-forward.
+        for (int k = iters; k < c.max_iters && k < 32; ++k) {
+            st->n_corr_iter[k] = nc;
+            for (int j = 0; j < 6; ++j) st->pose_iter[k][j] = pose[j];
+        }
+        iters = c.max_iters;
+        done = 1;
+    }
+    st->iter = iters;
+    st->done = done;
+    st->status = (nc < c.min_corr) ? 2 : 0;
+    if (!done) {
+        lio_pose_to_transform(pose, st->T, st->trig);              // MO:1613-1616 for the next pass
+    }
+}
+
+// Start of a registration: transformTobeMapped <- caller's guess, transform and
+// trig for the first pass, counters cleared.  matP / is_degenerate persist
+// (members MO:176-177).  Scans with N_s <= min_scan_pts are skipped (MO:1844).
+__global__ void k_s2m_init_state(LioScanState* __restrict__ st, int n_scans,
+                                 const float* __restrict__ poses, LioConsts c)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_scans) return;
+    LioScanState* p = &st[s];
+    float T[12], trig[6], pose[6];
+    for (int k = 0; k < 6; ++k) { pose[k] = poses[s * 6 + k]; p->pose[k] = pose[k]; }
+    lio_pose_to_transform(pose, T, trig);
+    for (int k = 0; k < 12; ++k) p->T[k] = T[k];
+    for (int k = 0; k < 6; ++k) p->trig[k] = trig[k];
+    p->iter = 0; p->converged = 0; p->n_corr_last = 0;
+    for (int k = 0; k < 32; ++k) { p->n_corr_iter[k] = 0; for (int j = 0; j < 6; ++j) p->pose_iter[k][j] = 0.0f; }
+    for (int k = 0; k < 36; ++k) p->AtA[k] = 0.0f;
+    for (int k = 0; k < 6; ++k) p->AtB[k] = 0.0f;
+    const bool enough = p->n_pts > c.min_scan_pts;
+    p->done = enough ? 0 : 1;
+    p->status = enough ? 0 : 1;
+}
+
+// One thread = one scan point (x PPT points, strided by the workgroup size).
+template <int PPT>
+__global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
+{
+    __shared__ double s_part[LIO_BLOCK / 64][28];
+    __shared__ double s_sum[28];
+    __shared__ LioSolveWs s_ws;
+
+    const LioBlockDesc bd = P.blocks[blockIdx.x];
+    LioScanState* st = &P.state[bd.scan];
+    if (st->done) return;                                  // workgroup-uniform
+
+    // wave-uniform per-scan values
+    float T[12], tr[6];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = st->T[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tr[k] = st->trig[k];
+    const int n_pts = st->n_pts;
+    const int base = st->offset;
+    const bool record = (P.rec_flag != nullptr) && (st->iter == P.c.record_iter);
+    const LioGrid g = P.grid;
+
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+
+#pragma unroll 1
+    for (int pp = 0; pp < PPT; ++pp) {
+        const int li = bd.first + pp * LIO_BLOCK + (int)threadIdx.x;
+        const bool in_range = li < n_pts;
+        const int gi = base + (in_range ? li : 0);
+        const float px = P.sx[gi], py = P.sy[gi], pz = P.sz[gi];     // coalesced SoA
+
+        // pointAssociateToMap, MO:841-847
+        const float qx = T[0] * px + T[1] * py + T[2]  * pz + T[3];
+        const float qy = T[4] * px + T[5] * py + T[6]  * pz + T[7];
+        const float qz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+
+        bool active = in_range;
+        if (P.shard.axis >= 0) {                                     // owner-computes (multi-GPU)
+            const float qa = P.shard.axis == 0 ? qx : (P.shard.axis == 1 ? qy : qz);
+            int gc = lio_cell_coord(qa, P.shard.gorigin, P.shard.inv_cell, P.shard.gdim);
+            gc = min(max(gc, 0), P.shard.gdim - 1);
+            active = active && gc >= P.shard.lo && gc < P.shard.hi;
+        }
+
+        // ---- exact 5-NN over the 27-cell neighbourhood (MO:1631) ----
+        const unsigned long long sentinel =
+            ((unsigned long long)__float_as_uint(P.c.max_sq_dist) << 32) | 0x7fffffffull;
+        LioTop5 top = { sentinel, sentinel, sentinel, sentinel, sentinel };
+        const int cx = lio_cell_coord(qx, g.ox, g.inv_cell, g.nx);
+        const int cy = lio_cell_coord(qy, g.oy, g.inv_cell, g.ny);
+        const int cz = lio_cell_coord(qz, g.oz, g.inv_cell, g.nz);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+        if (active && x0 <= x1) {
+#pragma unroll 1
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int z = cz + dz;
+                if (z < 0 || z >= g.nz) continue;
+#pragma unroll 1
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= g.ny) continue;
+                    const int row = (z * g.ny + y) * g.nx;
+                    const int beg = P.cell_start[row + x0];
+                    const int end = P.cell_start[row + x1 + 1];
+                    for (int j = beg; j < end; ++j) {
+                        const float4 m = P.map_sorted[j];
+                        const float d2 = lio_sqdist(m.x, m.y, m.z, qx, qy, qz);
+                        const unsigned long long key =
+                            ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(m.w);
+                        lio_top5_insert(top, key);
+                    }
+                }
+            }
+        }
+        // gate MO:1641: pointSearchSqDis[4] < 1.0
+        const float d4 = __uint_as_float((unsigned)(top.k4 >> 32));
+        bool ok = active && (d4 < P.c.max_sq_dist);
+
+        int nn[5] = { (int)(unsigned)top.k0, (int)(unsigned)top.k1, (int)(unsigned)top.k2,
+                      (int)(unsigned)top.k3, (int)(unsigned)top.k4 };
+        float cxx = 0.0f, cyy = 0.0f, czz = 0.0f, cww = 0.0f;
+        bool accept = false;
+        if (ok) {
+            // MO:1642-1646: neighbours in the caller's map order (original xyz)
+            float a[5][3], m[5][3];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int id = nn[j];
+                const float4 mp = P.map_xyz4[id];
+                m[j][0] = a[j][0] = mp.x;
+                m[j][1] = a[j][1] = mp.y;
+                m[j][2] = a[j][2] = mp.z;
+            }
+            float X0[3];
+            lio_plane_qr5x3(a, X0);                                  // MO:1648
+            float pa = X0[0], pb = X0[1], pc = X0[2], pd = 1;         // MO:1650-1653
+            const float ps = sqrtf(pa * pa + pb * pb + pc * pc);      // MO:1655
+            pa /= ps; pb /= ps; pc /= ps; pd /= ps;                   // MO:1656
+            bool planeValid = true;                                   // MO:1658-1666
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float v = fabsf(pa * m[j][0] + pb * m[j][1] + pc * m[j][2] + pd);
+                if ((double)v > P.c.plane_tol) planeValid = false;
+            }
+            if (planeValid) {
+                const float pd2 = pa * qx + pb * qy + pc * qz + pd;   // MO:1669
+                const float r2 = px * px + py * py + pz * pz;
+                // MO:1671-1672 (product, quotient and difference in double)
+                const float s = (float)(1 - P.c.weight * (double)fabsf(pd2) / (double)sqrtf(sqrtf(r2)));
+                cxx = s * pa; cyy = s * pb; czz = s * pc; cww = s * pd2;   // MO:1674-1677
+                accept = (double)s > P.c.min_s;                       // MO:1679
+            }
+        }
+        if (record && in_range) {
+            P.rec_flag[gi] = accept ? 1 : 0;
+            reinterpret_cast<float4*>(P.rec_coeff)[gi] = make_float4(cxx, cyy, czz, cww);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) P.rec_nn[(size_t)gi * 5 + j] = ok ? nn[j] : -1;
+        }
+        if (accept) {
+            // MO:1735-1783: row of matA/matB, outer products accumulated in double
+            float row[6], rhs;
+            lio_jacobian_row(tr, px, py, pz, cxx, cyy, czz, cww, P.c.jac_exact, row, rhs);
+            int p = 0;
+#pragma unroll
+            for (int a2 = 0; a2 < 6; ++a2)
+#pragma unroll
+                for (int b2 = a2; b2 < 6; ++b2) acc[p++] += (double)row[a2] * (double)row[b2];
+#pragma unroll
+            for (int a2 = 0; a2 < 6; ++a2) acc[21 + a2] += (double)row[a2] * (double)rhs;
+            acc[27] += 1.0;
+        }
+    }
+
+    // ---- workgroup reduction: wave butterfly -> LDS -> fixed-order sum ----
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 28; ++k) {
+        const double v = lio_wave_sum(acc[k]);
+        if (lane == 0) s_part[wave][k] = v;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+
+    double* part = P.partials + ((size_t)bd.scan * P.max_blk + bd.blk) * LIO_SUMS;
+    if (lane < 28) {
+        double v = s_part[0][lane];
+#pragma unroll
+        for (int w = 1; w < LIO_BLOCK / 64; ++w) v += s_part[w][lane];
+        // write-through (sc1) store: visible to the other XCDs without a release fence
+        __hip_atomic_store(part + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last = 0;
+    if (lane == 0) {
+        const unsigned old = atomicAdd(&P.arrive[bd.scan], 1u);
+        last = (old == (unsigned)bd.n_blk - 1u);
+    }
+    last = __shfl(last, 0);
+    if (!last) return;
+
+    // last workgroup of this scan: fixed-order sum over the scan's chunks
+    if (lane < 28) {
+        const double* base_p = P.partials + (size_t)bd.scan * P.max_blk * LIO_SUMS + lane;
+        double v = 0.0;
+        for (int b = 0; b < bd.n_blk; ++b)
+            v += __hip_atomic_load(base_p + (size_t)b * LIO_SUMS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_sum[lane] = v;
+        if (P.sums_out) P.sums_out[(size_t)bd.scan * LIO_SUMS + lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();      // same wave: LDS ops retire in order
+    if (lane == 0) {
+        P.arrive[bd.scan] = 0;            // re-arm for the next launch
+        if (!P.sums_out) lio_gn_step(st, s_sum, P.c, &s_ws);
+    }
+}
+
+// Sharded mode: solve every scan from all-reduced sums (one lane per scan).
+__global__ void k_s2m_apply(LioScanState* __restrict__ st, int n_scans, const double* __restrict__ sums, LioConsts c)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_scans) return;
+    if (st[s].done) return;
+    __shared__ LioSolveWs s_ws[64];
+    lio_gn_step(&st[s], sums + (size_t)s * LIO_SUMS, c, &s_ws[threadIdx.x]);
+}
+
+__global__ void k_s2m_count_active(const LioScanState* __restrict__ st, int n_scans, int* __restrict__ out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_scans && !st[s].done) atomicAdd(out, 1);
+}
+
+// ------------------------------------------------------------ launch glue
+void lio_launch_aos_to_soa(const void* src, size_t stride, int n, float* x, float* y, float* z,
+                           float4* xyz4, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_aos_to_soa, dim3((n + 255) / 256), dim3(256), 0, s,
+                       (const unsigned char*)src, stride, n, x, y, z, xyz4);
+}
+
+void lio_launch_map_bbox(const float* x, const float* y, const float* z, int n, unsigned* bbox, hipStream_t s)
+{
+    int blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_map_bbox, dim3(blocks), dim3(256), 0, s, x, y, z, n, bbox);
+}
+
+void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, const float* z, int n,
+                          int* cell_of, int* cell_count, int* cell_start, int* tile_sums,
+                          float4* sorted, hipStream_t s)
+{
+    const int nb = (n + 255) / 256;
+    (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
+    hipLaunchKernelGGL(k_map_cell_count, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, cell_count);
+    const int n_tiles = (g.n_cells + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, s, cell_count, g.n_cells, tile_sums);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(256), 0, s, tile_sums, n_tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_tiles), dim3(256), 0, s, cell_count, g.n_cells, tile_sums, cell_start);
+    (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);   // reused as the fill cursor
+    hipLaunchKernelGGL(k_map_scatter, dim3(nb), dim3(256), 0, s, x, y, z, n, cell_of, cell_start, cell_count, sorted);
+}
+
+int lio_scan_tiles(int n_cells) { return (n_cells + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE; }
+
+void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_s2m_init_state, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, poses, c);
+}
+
+void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, hipStream_t s)
+{
+    if (n_blocks <= 0) return;
+    switch (ppt) {
+    case 1: hipLaunchKernelGGL(k_s2m_iterate<1>, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, P); break;
+    case 2: hipLaunchKernelGGL(k_s2m_iterate<2>, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, P); break;
+    default: hipLaunchKernelGGL(k_s2m_iterate<4>, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, P); break;
+    }
+}
+
+void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_s2m_apply, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, sums, c);
+}
+
+void lio_launch_count_active(const LioScanState* st, int n_scans, int* out, hipStream_t s)
+{
+    (void)hipMemsetAsync(out, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_s2m_count_active, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, out);
+}

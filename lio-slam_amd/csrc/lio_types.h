@@ -1,0 +1,67 @@
+// lio_types.h -- device-resident layouts shared by the kernels and the C-ABI
+// implementation.  Names follow the reference's domain (scan, map, cell,
+// correspondence), MO = src/liorf/src/mapOptmization.cpp.
+#pragma once
+#include <stdint.h>
+
+#define LIO_SUMS 32          // per-scan sums: 21 upper JtJ + 6 Jtr + N_c + pad to 32 doubles
+#define LIO_SUM_NC 27
+#define LIO_BLOCK 256        // threads per association workgroup (4 waves)
+
+// Hash grid over the voxel-downsampled local map (laserCloudSurfFromMapDS,
+// MO:149).  cell(v) = floor((v - origin) * inv_cell), linear id x-fastest so
+// that three x-adjacent cells are one contiguous run of sorted points.
+struct LioGrid {
+    float ox, oy, oz;
+    float inv_cell;
+    int32_t nx, ny, nz;
+    int32_t n_cells;
+};
+
+// Owner-computes predicate for a map sharded across GPUs: a scan
+// point is processed by the rank owning the GLOBAL cell of its transformed
+// position along `axis`.
+struct LioShard {
+    float gorigin;      // global grid origin along the axis
+    float inv_cell;
+    int32_t axis;       // 0,1,2 ; -1 = not sharded (own everything)
+    int32_t gdim;       // global cell count along the axis
+    int32_t lo, hi;     // owned cell range [lo, hi)
+};
+
+struct LioConsts {
+    double plane_tol, weight, min_s, conv_deg, conv_cm;
+    float  max_sq_dist, eig_thresh;
+    int32_t min_corr, max_iters, jac_exact, force_all, record_iter, min_scan_pts;
+};
+
+// Per-scan Gauss-Newton state (transformTobeMapped MO:171, isDegenerate/matP
+// MO:176-177, plus the transform of updatePointAssociateToMap MO:1613-1616 and
+// the trig of LMOptimization MO:1714-1719, recomputed once per iteration by the
+// lane that solves the step).
+struct LioScanState {
+    float pose[6];
+    float T[12];
+    float trig[6];
+    int32_t n_pts;
+    int32_t offset;          // first point of this scan in the batch SoA
+    int32_t iter;            // iterations executed
+    int32_t done;
+    int32_t converged;
+    int32_t is_degenerate;
+    int32_t n_corr_last;
+    int32_t status;
+    float matP[36];
+    float AtA[36];
+    float AtB[6];
+    int32_t n_corr_iter[32];
+    float pose_iter[32][6];
+};
+
+// One association workgroup = one contiguous chunk of one scan.
+struct LioBlockDesc {
+    int32_t scan;
+    int32_t first;           // first point (index within the scan)
+    int32_t blk;             // chunk index within the scan
+    int32_t n_blk;           // chunks of this scan
+};

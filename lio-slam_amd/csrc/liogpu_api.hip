@@ -1,0 +1,696 @@
+// liogpu_api.hip -- implementation of the C ABI in include/liogpu.h.
+// Host-side orchestration only: device buffers, H2D/D2H, kernel launches on
+// the handle's HIP stream.  MO = /root/reference/src/liorf/src/mapOptmization.cpp.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../include/liogpu.h"
+#include "lio_kernels.h"
+#include "lio_types.h"
+
+static thread_local std::string g_last_error;
+
+static int lio_fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof(buf), "%s", what);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                              \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) return lio_fail(LIO_ERR_HIP, #expr, _e);            \
+    } while (0)
+
+template <typename T>
+static hipError_t lio_grow(T** p, size_t* cap, size_t need, double slack = 1.25)
+{
+    if (need <= *cap && *p) return hipSuccess;
+    if (*p) { hipError_t e = hipFree(*p); if (e != hipSuccess) return e; *p = nullptr; }
+    size_t n = (size_t)((double)need * slack) + 64;
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e == hipSuccess) *cap = n;
+    else *cap = 0;
+    return e;
+}
+
+struct lio_s2m_handle {
+    lio_s2m_config cfg;
+    LioConsts c;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+
+    // ---- resident local map (laserCloudSurfFromMapDS, MO:149) ----
+    bool has_map = false;
+    size_t n_map = 0;
+    float *d_mx = nullptr, *d_my = nullptr, *d_mz = nullptr; size_t cap_mxyz[3] = {0, 0, 0};
+    float4* d_map4 = nullptr;   size_t cap_map4 = 0;
+    float4* d_sorted = nullptr; size_t cap_sorted = 0;
+    int* d_cell_of = nullptr;   size_t cap_cell_of = 0;
+    int* d_cell_count = nullptr; size_t cap_cell_count = 0;
+    int* d_cell_start = nullptr; size_t cap_cell_start = 0;
+    int* d_tile_sums = nullptr;  size_t cap_tile_sums = 0;
+    unsigned* d_bbox = nullptr;
+    unsigned char* d_stage = nullptr; size_t cap_stage = 0;
+    LioGrid grid{};
+
+    // ---- resident scan batch (laserCloudSurfLastDS, MO:138) ----
+    int n_scans = 0;
+    size_t total_pts = 0;
+    float *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr; size_t cap_sxyz[3] = {0, 0, 0};
+    LioScanState* d_state = nullptr; size_t cap_state = 0;
+    std::vector<LioScanState> h_state;
+    float* d_poses = nullptr; size_t cap_poses = 0;
+    LioBlockDesc* d_blocks = nullptr; size_t cap_blocks = 0;
+    int n_blocks = 0, ppt = 1, max_blk = 1;
+    double* d_partials = nullptr; size_t cap_partials = 0;
+    unsigned* d_arrive = nullptr; size_t cap_arrive = 0;
+    bool poses_set = false, ran = false;
+
+    // correspondence record (debug / parity)
+    unsigned char* d_rec_flag = nullptr; size_t cap_rec_flag = 0;
+    float* d_rec_coeff = nullptr; size_t cap_rec_coeff = 0;
+    int* d_rec_nn = nullptr; size_t cap_rec_nn = 0;
+
+    // sharding
+    LioShard shard{};
+    float gorigin[3] = {0, 0, 0};
+    int gdims[3] = {0, 0, 0};
+    bool has_global = false;
+
+    // profiling
+    hipEvent_t ev[LIO_MAX_ITERS + 1];
+    hipEvent_t ev_map[2];
+    bool ev_ok = false;
+    lio_s2m_profile prof{};
+    int launches_this_run = 0;
+    int* d_active = nullptr;
+};
+
+extern "C" int lio_version(void) { return LIO_VERSION; }
+extern "C" const char* lio_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" void lio_s2m_default_config(lio_s2m_config* c)
+{
+    memset(c, 0, sizeof(*c));
+    c->k = 5;                 // MO:1631
+    c->max_sq_dist = 1.0f;    // MO:1641
+    c->plane_tol = 0.2;       // MO:1662
+    c->weight = 0.9;          // MO:1671
+    c->min_s = 0.1;           // MO:1679
+    c->min_corr = 50;         // MO:1722
+    c->max_iters = 30;        // MO:1848
+    c->eig_thresh = 100.0f;   // MO:1796
+    c->conv_deg = 0.05;       // MO:1833
+    c->conv_cm = 0.05;        // MO:1833
+    c->min_scan_pts = 30;     // MO:1844
+    c->jacobian_mode = 0;
+    c->force_all_iters = 0;
+    c->device_id = 0;
+    c->cell_size = 0.0f;
+    c->max_batch = 1;
+    c->max_scan_pts = 0;
+    c->record_corr_iter = -1;
+    c->kernel_variant = 0;
+    c->profile = 0;
+}
+
+static void lio_fill_consts(lio_s2m_handle* h)
+{
+    const lio_s2m_config& g = h->cfg;
+    h->c.plane_tol = g.plane_tol; h->c.weight = g.weight; h->c.min_s = g.min_s;
+    h->c.conv_deg = g.conv_deg; h->c.conv_cm = g.conv_cm;
+    h->c.max_sq_dist = g.max_sq_dist; h->c.eig_thresh = g.eig_thresh;
+    h->c.min_corr = g.min_corr; h->c.max_iters = g.max_iters;
+    h->c.jac_exact = g.jacobian_mode ? 1 : 0; h->c.force_all = g.force_all_iters ? 1 : 0;
+    h->c.record_iter = g.record_corr_iter; h->c.min_scan_pts = g.min_scan_pts;
+}
+
+extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
+{
+    if (!cfg || !out) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (cfg->k != 5) return lio_fail(LIO_ERR_ARG, "only k = 5 is supported (MO:1631)");
+    if (cfg->max_iters < 1 || cfg->max_iters > LIO_MAX_ITERS) return lio_fail(LIO_ERR_ARG, "max_iters out of range");
+    if (!(cfg->max_sq_dist > 0.0f)) return lio_fail(LIO_ERR_ARG, "max_sq_dist must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return lio_fail(LIO_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return lio_fail(LIO_ERR_ARG, "device_id out of range");
+    HIPCHK(hipSetDevice(cfg->device_id));
+    lio_s2m_handle* h = new lio_s2m_handle();
+    h->cfg = *cfg;
+    if (h->cfg.cell_size > 0.0f && h->cfg.cell_size < sqrtf(h->cfg.max_sq_dist) * 1.001f) {
+        delete h;
+        return lio_fail(LIO_ERR_ARG, "cell_size must be >= sqrt(max_sq_dist)*1.001 for an exact 27-cell search");
+    }
+    lio_fill_consts(h);
+    h->shard.axis = -1;
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i <= LIO_MAX_ITERS; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
+    HIPCHK(hipEventCreate(&h->ev_map[0]));
+    HIPCHK(hipEventCreate(&h->ev_map[1]));
+    h->ev_ok = true;
+    HIPCHK(hipMalloc((void**)&h->d_bbox, 6 * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void**)&h->d_active, sizeof(int)));
+    *out = h;
+    return LIO_OK;
+}
+
+extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device_id);
+    (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = { h->d_mx, h->d_my, h->d_mz, h->d_map4, h->d_sorted, h->d_cell_of, h->d_cell_count,
+                     h->d_cell_start, h->d_tile_sums, h->d_bbox, h->d_stage, h->d_sx, h->d_sy, h->d_sz,
+                     h->d_state, h->d_poses, h->d_blocks, h->d_partials, h->d_arrive, h->d_rec_flag,
+                     h->d_rec_coeff, h->d_rec_nn, h->d_active };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->ev_ok) {
+        for (int i = 0; i <= LIO_MAX_ITERS; ++i) (void)hipEventDestroy(h->ev[i]);
+        (void)hipEventDestroy(h->ev_map[0]);
+        (void)hipEventDestroy(h->ev_map[1]);
+    }
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int lio_s2m_set_stream(lio_s2m_handle* h, void* hip_stream)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->stream) HIPCHK(hipStreamDestroy(h->stream));
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return LIO_OK;
+}
+
+static float lio_ord2f(unsigned u)
+{
+    unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+// ------------------------------------------------------------------ set_map
+extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, size_t stride)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    if (n > 0 && !pts) return lio_fail(LIO_ERR_ARG, "null map pointer");
+    if (stride < 12 || (stride & 3)) return lio_fail(LIO_ERR_ARG, "stride_bytes must be >= 12 and a multiple of 4");
+    if (n > 0x7fffffffull - 1024) return lio_fail(LIO_ERR_CAPACITY, "map too large");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    auto t0 = std::chrono::steady_clock::now();
+    h->has_map = false;
+    h->n_map = n;
+    const size_t nn = n ? n : 1;
+    HIPCHK(lio_grow(&h->d_mx, &h->cap_mxyz[0], nn));
+    HIPCHK(lio_grow(&h->d_my, &h->cap_mxyz[1], nn));
+    HIPCHK(lio_grow(&h->d_mz, &h->cap_mxyz[2], nn));
+    HIPCHK(lio_grow(&h->d_map4, &h->cap_map4, nn));
+    HIPCHK(lio_grow(&h->d_sorted, &h->cap_sorted, nn));
+    HIPCHK(lio_grow(&h->d_cell_of, &h->cap_cell_of, nn));
+    HIPCHK(lio_grow(&h->d_stage, &h->cap_stage, nn * stride));
+    if (n) {
+        HIPCHK(hipMemcpyAsync(h->d_stage, pts, n * stride, hipMemcpyHostToDevice, h->stream));
+        lio_launch_aos_to_soa(h->d_stage, stride, (int)n, h->d_mx, h->d_my, h->d_mz, h->d_map4, h->stream);
+    }
+    // bounding box on the device
+    unsigned init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+    HIPCHK(hipMemcpyAsync(h->d_bbox, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    if (n) lio_launch_map_bbox(h->d_mx, h->d_my, h->d_mz, (int)n, h->d_bbox, h->stream);
+    unsigned hb[6];
+    HIPCHK(hipMemcpyAsync(hb, h->d_bbox, sizeof(hb), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    auto t1 = std::chrono::steady_clock::now();
+
+    float mn[3], mx[3];
+    bool empty = (n == 0) || hb[0] == 0xffffffffu;
+    for (int a = 0; a < 3; ++a) { mn[a] = empty ? 0.0f : lio_ord2f(hb[a]); mx[a] = empty ? 0.0f : lio_ord2f(hb[3 + a]); }
+
+    float cell = h->cfg.cell_size > 0.0f ? h->cfg.cell_size : sqrtf(h->cfg.max_sq_dist) * 1.001f;
+    LioGrid g;
+    for (;;) {
+        g.inv_cell = 1.0f / cell;
+        g.ox = mn[0] - 0.5f * cell; g.oy = mn[1] - 0.5f * cell; g.oz = mn[2] - 0.5f * cell;
+        const double ex = ((double)mx[0] - g.ox) * g.inv_cell, ey = ((double)mx[1] - g.oy) * g.inv_cell,
+                     ez = ((double)mx[2] - g.oz) * g.inv_cell;
+        const double cells = (floor(ex) + 2.0) * (floor(ey) + 2.0) * (floor(ez) + 2.0);
+        if (cells <= 256.0 * 1024.0 * 1024.0) {
+            g.nx = (int)floor(ex) + 2; g.ny = (int)floor(ey) + 2; g.nz = (int)floor(ez) + 2;
+            g.n_cells = g.nx * g.ny * g.nz;
+            break;
+        }
+        cell *= 1.5f;   // larger cells keep the 27-cell search exact, only less selective
+    }
+    h->grid = g;
+    HIPCHK(lio_grow(&h->d_cell_count, &h->cap_cell_count, (size_t)g.n_cells));
+    HIPCHK(lio_grow(&h->d_cell_start, &h->cap_cell_start, (size_t)g.n_cells + 1));
+    HIPCHK(lio_grow(&h->d_tile_sums, &h->cap_tile_sums, (size_t)lio_scan_tiles(g.n_cells) + 1));
+
+    HIPCHK(hipEventRecord(h->ev_map[0], h->stream));
+    if (n) {
+        lio_launch_map_build(g, h->d_mx, h->d_my, h->d_mz, (int)n, h->d_cell_of, h->d_cell_count,
+                             h->d_cell_start, h->d_tile_sums, h->d_sorted, h->stream);
+    } else {
+        HIPCHK(hipMemsetAsync(h->d_cell_start, 0, sizeof(int) * ((size_t)g.n_cells + 1), h->stream));
+    }
+    HIPCHK(hipEventRecord(h->ev_map[1], h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev_map[0], h->ev_map[1]));
+    h->prof.map_build_ms = ms;
+    h->prof.map_upload_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    h->prof.n_map = (int64_t)n;
+    h->prof.n_cells = g.n_cells;
+    h->has_map = true;
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_set_global_grid(lio_s2m_handle* h, const float origin[3], const int32_t dims[3])
+{
+    if (!h || !origin || !dims) return lio_fail(LIO_ERR_ARG, "null argument");
+    for (int a = 0; a < 3; ++a) { h->gorigin[a] = origin[a]; h->gdims[a] = dims[a]; }
+    h->has_global = true;
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_set_shard(lio_s2m_handle* h, int32_t axis, int32_t lo, int32_t hi)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    if (axis < 0) { h->shard.axis = -1; return LIO_OK; }
+    if (axis > 2 || !h->has_global) return lio_fail(LIO_ERR_ARG, "set_global_grid first; axis in 0..2");
+    const float cell = h->cfg.cell_size > 0.0f ? h->cfg.cell_size : sqrtf(h->cfg.max_sq_dist) * 1.001f;
+    h->shard.axis = axis;
+    h->shard.gorigin = h->gorigin[axis];
+    h->shard.inv_cell = 1.0f / cell;
+    h->shard.gdim = h->gdims[axis];
+    h->shard.lo = lo;
+    h->shard.hi = hi;
+    return LIO_OK;
+}
+
+// ------------------------------------------------------------------- batch
+extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const void* const* scans,
+                                    const size_t* n_pts, size_t stride)
+{
+    if (!h || !scans || !n_pts) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (n_scans < 1) return lio_fail(LIO_ERR_ARG, "n_scans must be >= 1");
+    if (stride < 12 || (stride & 3)) return lio_fail(LIO_ERR_ARG, "stride_bytes must be >= 12 and a multiple of 4");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    size_t total = 0, max_n = 0;
+    for (int s = 0; s < n_scans; ++s) {
+        if (n_pts[s] && !scans[s]) return lio_fail(LIO_ERR_ARG, "null scan pointer");
+        total += n_pts[s];
+        if (n_pts[s] > max_n) max_n = n_pts[s];
+    }
+    if (total > 0x7fffffffull - 1024) return lio_fail(LIO_ERR_CAPACITY, "batch too large");
+    const size_t tt = total ? total : 1;
+    HIPCHK(lio_grow(&h->d_sx, &h->cap_sxyz[0], tt));
+    HIPCHK(lio_grow(&h->d_sy, &h->cap_sxyz[1], tt));
+    HIPCHK(lio_grow(&h->d_sz, &h->cap_sxyz[2], tt));
+    HIPCHK(lio_grow(&h->d_stage, &h->cap_stage, tt * stride));
+    HIPCHK(lio_grow(&h->d_state, &h->cap_state, (size_t)n_scans));
+    HIPCHK(lio_grow(&h->d_poses, &h->cap_poses, (size_t)n_scans * 6));
+    HIPCHK(lio_grow(&h->d_arrive, &h->cap_arrive, (size_t)n_scans));
+
+    // launch geometry: one workgroup = LIO_BLOCK * ppt consecutive points of one scan
+    int ppt = h->cfg.kernel_variant;
+    if (ppt != 1 && ppt != 2 && ppt != 4) {
+        const size_t blocks1 = (total + LIO_BLOCK - 1) / LIO_BLOCK + (size_t)n_scans;
+        ppt = blocks1 > 16384 ? 4 : (blocks1 > 4096 ? 2 : 1);
+    }
+    h->ppt = ppt;
+    const size_t per_blk = (size_t)LIO_BLOCK * ppt;
+    std::vector<LioBlockDesc> blocks;
+    int max_blk = 1;
+    const size_t old_scans = h->h_state.size();
+    h->h_state.resize((size_t)n_scans);
+    size_t off = 0;
+    for (int s = 0; s < n_scans; ++s) {
+        LioScanState& st = h->h_state[s];
+        if ((size_t)s >= old_scans) memset(&st, 0, sizeof(st));   // keep matP / is_degenerate of live slots
+        st.n_pts = (int)n_pts[s];
+        st.offset = (int)off;
+        st.done = 1;
+        const int nb = (int)((n_pts[s] + per_blk - 1) / per_blk);
+        if (nb > max_blk) max_blk = nb;
+        for (int b = 0; b < nb; ++b) blocks.push_back({ s, (int)(b * per_blk), b, nb });
+        if (n_pts[s])
+            HIPCHK(hipMemcpyAsync(h->d_stage + off * stride, scans[s], n_pts[s] * stride,
+                                  hipMemcpyHostToDevice, h->stream));
+        off += n_pts[s];
+    }
+    h->n_scans = n_scans;
+    h->total_pts = total;
+    h->n_blocks = (int)blocks.size();
+    h->max_blk = max_blk;
+    HIPCHK(lio_grow(&h->d_blocks, &h->cap_blocks, blocks.size() ? blocks.size() : 1));
+    HIPCHK(lio_grow(&h->d_partials, &h->cap_partials, (size_t)n_scans * max_blk * LIO_SUMS));
+    if (h->cfg.record_corr_iter >= 0) {
+        HIPCHK(lio_grow(&h->d_rec_flag, &h->cap_rec_flag, tt));
+        HIPCHK(lio_grow(&h->d_rec_coeff, &h->cap_rec_coeff, tt * 4));
+        HIPCHK(lio_grow(&h->d_rec_nn, &h->cap_rec_nn, tt * 5));
+        HIPCHK(hipMemsetAsync(h->d_rec_flag, 0, tt, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_rec_coeff, 0, tt * 4 * sizeof(float), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_rec_nn, 0xff, tt * 5 * sizeof(int), h->stream));
+    }
+    if (total) lio_launch_aos_to_soa(h->d_stage, stride, (int)total, h->d_sx, h->d_sy, h->d_sz, nullptr, h->stream);
+    if (!blocks.empty())
+        HIPCHK(hipMemcpyAsync(h->d_blocks, blocks.data(), blocks.size() * sizeof(LioBlockDesc),
+                              hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_state, h->h_state.data(), (size_t)n_scans * sizeof(LioScanState),
+                          hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_arrive, 0, (size_t)n_scans * sizeof(unsigned), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));   // `blocks` and the caller's scans are borrowed only for this call
+    HIPCHK(hipGetLastError());
+    h->poses_set = false;
+    h->ran = false;
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
+{
+    if (!h || !poses) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (h->n_scans < 1) return lio_fail(LIO_ERR_ARG, "no batch uploaded");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_scans * 6 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->poses_set = true;
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_set_degeneracy(lio_s2m_handle* h, int32_t scan, const float matP[36], int32_t is_degenerate)
+{
+    if (!h || !matP) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (scan < 0 || scan >= h->n_scans) return lio_fail(LIO_ERR_ARG, "scan slot out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    LioScanState& st = h->h_state[scan];
+    memcpy(st.matP, matP, sizeof(float) * 36);
+    st.is_degenerate = is_degenerate;
+    char* base = (char*)(h->d_state + scan);
+    HIPCHK(hipMemcpyAsync(base + offsetof(LioScanState, matP), st.matP, sizeof(float) * 36, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(base + offsetof(LioScanState, is_degenerate), &st.is_degenerate, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LIO_OK;
+}
+
+static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_out)
+{
+    P.grid = h->grid;
+    P.shard = h->shard;
+    P.c = h->c;
+    P.map_sorted = h->d_sorted;
+    P.map_xyz4 = h->d_map4;
+    P.cell_start = h->d_cell_start;
+    P.sx = h->d_sx; P.sy = h->d_sy; P.sz = h->d_sz;
+    P.state = h->d_state;
+    P.blocks = h->d_blocks;
+    P.partials = h->d_partials;
+    P.arrive = h->d_arrive;
+    P.max_blk = h->max_blk;
+    P.sums_out = sums_out;
+    const bool rec = h->cfg.record_corr_iter >= 0;
+    P.rec_flag = rec ? h->d_rec_flag : nullptr;
+    P.rec_coeff = rec ? h->d_rec_coeff : nullptr;
+    P.rec_nn = rec ? h->d_rec_nn : nullptr;
+}
+
+extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    if (!h->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
+    if (h->n_scans < 1 || !h->poses_set) return lio_fail(LIO_ERR_ARG, "batch_upload and batch_set_poses first");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->c, h->stream);
+    h->launches_this_run = 0;
+    h->ran = true;
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
+{
+    int rc = lio_s2m_batch_begin(h);
+    if (rc != LIO_OK) return rc;
+    LioIterParams P;
+    lio_fill_params(h, P, nullptr);
+    const bool prof = h->cfg.profile != 0;
+    if (prof) HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    for (int it = 0; it < h->cfg.max_iters; ++it) {      // MO:1848
+        lio_launch_iterate(P, h->n_blocks, h->ppt, h->stream);
+        if (prof) HIPCHK(hipEventRecord(h->ev[it + 1], h->stream));
+    }
+    h->launches_this_run = h->cfg.max_iters;
+    HIPCHK(hipGetLastError());
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
+{
+    if (!h || !d_sums) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (!h->ran) return lio_fail(LIO_ERR_ARG, "batch_begin first");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    LioIterParams P;
+    lio_fill_params(h, P, d_sums);
+    HIPCHK(hipMemsetAsync(d_sums, 0, (size_t)h->n_scans * LIO_SUMS * sizeof(double), h->stream));
+    lio_launch_iterate(P, h->n_blocks, h->ppt, h->stream);
+    h->launches_this_run++;
+    HIPCHK(hipGetLastError());
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_batch_iter_apply(lio_s2m_handle* h, const double* d_sums)
+{
+    if (!h || !d_sums) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (!h->ran) return lio_fail(LIO_ERR_ARG, "batch_begin first");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    lio_launch_apply(h->d_state, h->n_scans, d_sums, h->c, h->stream);
+    HIPCHK(hipGetLastError());
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_batch_n_active(lio_s2m_handle* h, int32_t* n_active)
+{
+    if (!h || !n_active) return lio_fail(LIO_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    lio_launch_count_active(h->d_state, h->n_scans, h->d_active, h->stream);
+    int v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *n_active = v;
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_batch_sync(lio_s2m_handle* h)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_result* results)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    if (!h->ran) return lio_fail(LIO_ERR_ARG, "nothing has been run");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(h->h_state.data(), h->d_state, (size_t)h->n_scans * sizeof(LioScanState),
+                          hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    int64_t pit = 0;
+    for (int s = 0; s < h->n_scans; ++s) {
+        const LioScanState& st = h->h_state[s];
+        if (poses) memcpy(poses + (size_t)s * 6, st.pose, sizeof(float) * 6);
+        // a "< 50 correspondences" scan was fast-forwarded: it did its work once
+        pit += (int64_t)st.n_pts * (st.status == 2 ? 1 : st.iter) * (st.status == 1 ? 0 : 1);
+        if (results) {
+            lio_s2m_result& r = results[s];
+            memset(&r, 0, sizeof(r));
+            r.status = st.status;
+            r.iters = st.status == 1 ? 0 : st.iter;
+            r.converged = st.converged;
+            r.is_degenerate = st.is_degenerate;
+            r.n_corr_last = st.n_corr_last;
+            memcpy(r.n_corr_iter, st.n_corr_iter, sizeof(r.n_corr_iter));
+            memcpy(r.matP, st.matP, sizeof(r.matP));
+            memcpy(r.AtA, st.AtA, sizeof(r.AtA));
+            memcpy(r.AtB, st.AtB, sizeof(r.AtB));
+            memcpy(r.pose_iter, st.pose_iter, sizeof(r.pose_iter));
+        }
+    }
+    h->prof.point_iters = pit;
+    h->prof.n_launches = h->launches_this_run;
+    if (h->cfg.profile && h->launches_this_run > 0 && h->launches_this_run <= LIO_MAX_ITERS) {
+        for (int i = 0; i < h->launches_this_run; ++i) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = -1.0f;
+            h->prof.launch_ms[i] = ms;
+        }
+    }
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_register(lio_s2m_handle* h, const void* scan, size_t n, size_t stride,
+                                float pose[6], lio_s2m_result* res)
+{
+    if (!h || !pose) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (!h->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
+    const void* scans[1] = { scan };
+    size_t np[1] = { n };
+    int rc;
+    if ((rc = lio_s2m_batch_upload(h, 1, scans, np, stride)) != LIO_OK) return rc;
+    if ((rc = lio_s2m_batch_set_poses(h, pose)) != LIO_OK) return rc;
+    if ((rc = lio_s2m_batch_run(h)) != LIO_OK) return rc;
+    lio_s2m_result local;
+    if ((rc = lio_s2m_batch_results(h, pose, res ? res : &local)) != LIO_OK) return rc;
+    return (res ? res : &local)->status;
+}
+
+extern "C" int lio_s2m_get_correspondences(lio_s2m_handle* h, int32_t scan, uint8_t* flag,
+                                           float* coeff4, int32_t* nn_idx5)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    if (h->cfg.record_corr_iter < 0) return lio_fail(LIO_ERR_ARG, "record_corr_iter was not set at create time");
+    if (scan < 0 || scan >= h->n_scans) return lio_fail(LIO_ERR_ARG, "scan slot out of range");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const size_t off = (size_t)h->h_state[scan].offset, n = (size_t)h->h_state[scan].n_pts;
+    if (n == 0) return LIO_OK;
+    if (flag) HIPCHK(hipMemcpyAsync(flag, h->d_rec_flag + off, n, hipMemcpyDeviceToHost, h->stream));
+    if (coeff4) HIPCHK(hipMemcpyAsync(coeff4, h->d_rec_coeff + off * 4, n * 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (nn_idx5) HIPCHK(hipMemcpyAsync(nn_idx5, h->d_rec_nn + off * 5, n * 5 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_get_profile(lio_s2m_handle* h, lio_s2m_profile* out)
+{
+    if (!h || !out) return lio_fail(LIO_ERR_ARG, "null argument");
+    *out = h->prof;
+    return LIO_OK;
+}
+
+int lio_fail_ext(int code, const char* what, hipError_t e) { return lio_fail(code, what, e); }
+
+// ------------------------------------------------------ host-side scalar code
+// transformUpdate, MO:1867-1897: roll/pitch are slerp-blended towards the IMU
+// attitude with tf (Bullet) quaternions in fp64, then clamped (MO:1892-1894,
+// constraintTransformation MO:1899-1907).  tf::Quaternion::setRPY / slerp /
+// tf::Matrix3x3::getRPY restated from their published formulas.
+namespace {
+struct Quat { double x, y, z, w; };
+
+Quat quat_from_rpy(double roll, double pitch, double yaw)
+{
+    const double hy = yaw * 0.5, hp = pitch * 0.5, hr = roll * 0.5;
+    const double cy = cos(hy), sy = sin(hy), cp = cos(hp), sp = sin(hp), cr = cos(hr), sr = sin(hr);
+    return { sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy,
+             cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy };
+}
+
+double quat_dot(const Quat& a, const Quat& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+Quat quat_slerp(const Quat& a, const Quat& q, double t)
+{
+    const double s = sqrt(quat_dot(a, a) * quat_dot(q, q));
+    const double d = quat_dot(a, q);
+    const double theta = ((d < 0) ? acos(-d / s) * 2.0 : acos(d / s) * 2.0) / 2.0;   // angleShortestPath / 2
+    if (theta != 0.0) {
+        const double inv = 1.0 / sin(theta);
+        const double s0 = sin((1.0 - t) * theta), s1 = sin(t * theta);
+        if (d < 0)
+            return { (a.x * s0 + -q.x * s1) * inv, (a.y * s0 + -q.y * s1) * inv,
+                     (a.z * s0 + -q.z * s1) * inv, (a.w * s0 + -q.w * s1) * inv };
+        return { (a.x * s0 + q.x * s1) * inv, (a.y * s0 + q.y * s1) * inv,
+                 (a.z * s0 + q.z * s1) * inv, (a.w * s0 + q.w * s1) * inv };
+    }
+    return a;
+}
+
+void quat_to_rpy(const Quat& q, double& roll, double& pitch, double& yaw)
+{
+    const double s = 2.0 / quat_dot(q, q);
+    const double xs = q.x * s, ys = q.y * s, zs = q.z * s;
+    const double wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+    const double xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+    const double yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+    const double m00 = 1.0 - (yy + zz), m10 = xy + wz, m20 = xz - wy, m21 = yz + wx, m22 = 1.0 - (xx + yy);
+    if (fabs(m20) >= 1) {
+        yaw = 0;
+        const double delta = atan2(m21, m22);
+        pitch = (m20 < 0) ? M_PI / 2.0 : -M_PI / 2.0;
+        roll = delta;
+    } else {
+        pitch = -asin(m20);
+        const double cp = cos(pitch);
+        roll = atan2(m21 / cp, m22 / cp);
+        yaw = atan2(m10 / cp, m00 / cp);
+    }
+}
+
+float clamp_abs(float v, float limit)
+{
+    if (v < -limit) v = -limit;
+    if (v > limit) v = limit;
+    return v;
+}
+}  // namespace
+
+extern "C" void lio_transform_update(float pose[6], int32_t imu_available, int32_t imu_type,
+                                     float imu_roll_init, float imu_pitch_init, float imu_rpy_weight,
+                                     float rotation_tollerance, float z_tollerance)
+{
+    if (imu_available && imu_type) {                     // MO:1869
+        if (fabsf(imu_pitch_init) < 1.4) {               // MO:1871
+            const double w = imu_rpy_weight;
+            double r, p, y;
+            quat_to_rpy(quat_slerp(quat_from_rpy(pose[0], 0, 0), quat_from_rpy(imu_roll_init, 0, 0), w), r, p, y);
+            pose[0] = (float)r;                          // MO:1879-1882
+            quat_to_rpy(quat_slerp(quat_from_rpy(0, pose[1], 0), quat_from_rpy(0, imu_pitch_init, 0), w), r, p, y);
+            pose[1] = (float)p;                          // MO:1885-1888
+        }
+    }
+    pose[0] = clamp_abs(pose[0], rotation_tollerance);   // MO:1892
+    pose[1] = clamp_abs(pose[1], rotation_tollerance);   // MO:1893
+    pose[5] = clamp_abs(pose[5], z_tollerance);          // MO:1894
+}
+
+// imuDeskewInfo, IP:359-418: gyro integration over [timeScanCur-0.01, timeScanEnd+0.01]
+extern "C" int lio_imu_deskew_info(const double* stamp, const double* gx, const double* gy, const double* gz,
+                                   int32_t n_imu, double t_cur, double t_end,
+                                   double* imuTime, double* imuRotX, double* imuRotY, double* imuRotZ)
+{
+    if (!stamp || !gx || !gy || !gz || !imuTime || !imuRotX || !imuRotY || !imuRotZ) return 0;
+    int i = 0;
+    while (i < n_imu && stamp[i] < t_cur - 0.01) ++i;    // IP:363-369
+    if (i >= n_imu) return 0;                            // IP:371-372
+    int cur = 0;
+    for (; i < n_imu; ++i) {
+        const double t = stamp[i];
+        if (t > t_end + 0.01) break;                     // IP:387-388
+        if (cur == 0) {                                  // IP:390-397
+            imuRotX[0] = 0; imuRotY[0] = 0; imuRotZ[0] = 0; imuTime[0] = t;
+            cur = 1;
+            continue;
+        }
+        if (cur >= 2000) break;                          // table length, IP:62
+        const double dt = t - imuTime[cur - 1];          // IP:404
+        imuRotX[cur] = imuRotX[cur - 1] + gx[i] * dt;    // IP:405-407
+        imuRotY[cur] = imuRotY[cur - 1] + gy[i] * dt;
+        imuRotZ[cur] = imuRotZ[cur - 1] + gz[i] * dt;
+        imuTime[cur] = t;
+        ++cur;
+    }
+    return cur - 1;                                      // IP:412
+}
