@@ -64,6 +64,8 @@ typedef struct lio_s2m_config {
                                 lio_s2m_get_correspondences (-1 = none)                    */
     int32_t kernel_variant;  /* 0 = auto; >0 selects an association kernel (A/B testing)   */
     int32_t profile;         /* 1 = bracket every GN-iteration launch with HIP events      */
+    int32_t lookahead;       /* GN launches enqueued ahead of the convergence check;
+                                0 = never enqueue an empty launch, -1 = auto               */
 } lio_s2m_config;
 
 /* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in
@@ -86,6 +88,7 @@ typedef struct lio_s2m_profile {
     float   map_upload_ms;     /* last set_map: wall time of staging + H2D                */
     int32_t n_launches;        /* GN-iteration launches of the last run                   */
     float   launch_ms[LIO_MAX_ITERS]; /* device time of each (profile=1)                 */
+    int32_t launch_active[LIO_MAX_ITERS]; /* scans that took part in each launch           */
     int64_t point_iters;       /* scan points processed by active scans over the run      */
     int64_t n_map;             /* resident map points                                     */
     int64_t n_cells;           /* grid cells                                              */

@@ -30,7 +30,7 @@ class S2MConfig(C.Structure):
         ("min_scan_pts", C.c_int32), ("jacobian_mode", C.c_int32), ("force_all_iters", C.c_int32),
         ("device_id", C.c_int32), ("cell_size", C.c_float), ("max_batch", C.c_int32),
         ("max_scan_pts", C.c_int32), ("record_corr_iter", C.c_int32), ("kernel_variant", C.c_int32),
-        ("profile", C.c_int32),
+        ("profile", C.c_int32), ("lookahead", C.c_int32),
     ]
 
 
@@ -47,7 +47,8 @@ class S2MResult(C.Structure):
 class S2MProfile(C.Structure):
     _fields_ = [
         ("map_build_ms", C.c_float), ("map_upload_ms", C.c_float), ("n_launches", C.c_int32),
-        ("launch_ms", C.c_float * LIO_MAX_ITERS), ("point_iters", C.c_int64),
+        ("launch_ms", C.c_float * LIO_MAX_ITERS), ("launch_active", C.c_int32 * LIO_MAX_ITERS),
+        ("point_iters", C.c_int64),
         ("n_map", C.c_int64), ("n_cells", C.c_int64),
     ]
 

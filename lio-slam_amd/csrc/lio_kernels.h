@@ -19,6 +19,7 @@ struct LioIterParams {
     double* partials;              // [scan][max_blk][LIO_SUMS]
     unsigned* arrive;              // [scan] arrival counters
     int max_blk;
+    int* n_active;                 // scans still iterating (device counter)
     double* sums_out;              // sharded mode: [scan][LIO_SUMS]; nullptr = solve in place
     unsigned char* rec_flag;       // optional correspondence record (iteration c.record_iter)
     float* rec_coeff;
@@ -32,7 +33,8 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
                           int* cell_of, int* cell_count, int* cell_start, int* tile_sums,
                           float4* sorted, hipStream_t s);
 int  lio_scan_tiles(int n_cells);
-void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c, hipStream_t s);
+void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c,
+                           int* n_active, hipStream_t s);
 void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, hipStream_t s);
-void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c, hipStream_t s);
-void lio_launch_count_active(const LioScanState* st, int n_scans, int* out, hipStream_t s);
+void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
+                      int* n_active, hipStream_t s);

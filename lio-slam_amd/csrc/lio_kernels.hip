@@ -224,7 +224,8 @@ LIO_DEV double lio_wave_sum(double v)
 // The serial Gauss-Newton step of one scan: LMOptimization MO:1702-1837 from
 // the reduced sums onward, plus the loop control of scan2MapOptimization
 // MO:1848-1859.  One lane; `ws` is LDS (or any) working storage.
-__device__ static void lio_gn_step(LioScanState* st, const double* sums, const LioConsts& c, LioSolveWs* ws)
+__device__ static void lio_gn_step(LioScanState* st, const double* sums, const LioConsts& c, LioSolveWs* ws,
+                                   int* n_active)
 {
     const int it = st->iter;
     const int nc = (int)sums[LIO_SUM_NC];
@@ -298,6 +299,7 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
     st->iter = iters;
     st->done = done;
     st->status = (nc < c.min_corr) ? 2 : 0;
+    if (done && n_active) atomicSub(n_active, 1);
     if (!done) {
         lio_pose_to_transform(pose, st->T, st->trig);              // MO:1613-1616 for the next pass
     }
@@ -307,7 +309,7 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
 // trig for the first pass, counters cleared.  matP / is_degenerate persist
 // (members MO:176-177).  Scans with N_s <= min_scan_pts are skipped (MO:1844).
 __global__ void k_s2m_init_state(LioScanState* __restrict__ st, int n_scans,
-                                 const float* __restrict__ poses, LioConsts c)
+                                 const float* __restrict__ poses, LioConsts c, int* __restrict__ n_active)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_scans) return;
@@ -324,6 +326,7 @@ __global__ void k_s2m_init_state(LioScanState* __restrict__ st, int n_scans,
     const bool enough = p->n_pts > c.min_scan_pts;
     p->done = enough ? 0 : 1;
     p->status = enough ? 0 : 1;
+    if (enough) atomicAdd(n_active, 1);
 }
 
 // One thread = one scan point (x PPT points, strided by the workgroup size).
@@ -502,24 +505,19 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
     __builtin_amdgcn_wave_barrier();      // same wave: LDS ops retire in order
     if (lane == 0) {
         P.arrive[bd.scan] = 0;            // re-arm for the next launch
-        if (!P.sums_out) lio_gn_step(st, s_sum, P.c, &s_ws);
+        if (!P.sums_out) lio_gn_step(st, s_sum, P.c, &s_ws, P.n_active);
     }
 }
 
 // Sharded mode: solve every scan from all-reduced sums (one lane per scan).
-__global__ void k_s2m_apply(LioScanState* __restrict__ st, int n_scans, const double* __restrict__ sums, LioConsts c)
+__global__ void k_s2m_apply(LioScanState* __restrict__ st, int n_scans, const double* __restrict__ sums, LioConsts c,
+                            int* __restrict__ n_active)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_scans) return;
     if (st[s].done) return;
     __shared__ LioSolveWs s_ws[64];
-    lio_gn_step(&st[s], sums + (size_t)s * LIO_SUMS, c, &s_ws[threadIdx.x]);
-}
-
-__global__ void k_s2m_count_active(const LioScanState* __restrict__ st, int n_scans, int* __restrict__ out)
-{
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n_scans && !st[s].done) atomicAdd(out, 1);
+    lio_gn_step(&st[s], sums + (size_t)s * LIO_SUMS, c, &s_ws[threadIdx.x], n_active);
 }
 
 // ------------------------------------------------------------ launch glue
@@ -555,9 +553,11 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
 
 int lio_scan_tiles(int n_cells) { return (n_cells + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE; }
 
-void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c, hipStream_t s)
+void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c,
+                           int* n_active, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_s2m_init_state, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, poses, c);
+    (void)hipMemsetAsync(n_active, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_s2m_init_state, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, poses, c, n_active);
 }
 
 void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, hipStream_t s)
@@ -570,13 +570,8 @@ void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, hipStream
     }
 }
 
-void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c, hipStream_t s)
+void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
+                      int* n_active, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_s2m_apply, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, sums, c);
-}
-
-void lio_launch_count_active(const LioScanState* st, int n_scans, int* out, hipStream_t s)
-{
-    (void)hipMemsetAsync(out, 0, sizeof(int), s);
-    hipLaunchKernelGGL(k_s2m_count_active, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, out);
+    hipLaunchKernelGGL(k_s2m_apply, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, sums, c, n_active);
 }

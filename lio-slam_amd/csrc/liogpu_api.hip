@@ -87,8 +87,9 @@ struct lio_s2m_handle {
     bool has_global = false;
 
     // profiling
-    hipEvent_t ev[LIO_MAX_ITERS + 1];
+    hipEvent_t ev_beg[LIO_MAX_ITERS], ev_end[LIO_MAX_ITERS], ev_chk[LIO_MAX_ITERS];
     hipEvent_t ev_map[2];
+    int* h_active = nullptr;          // pinned: active-scan count after each launch
     bool ev_ok = false;
     lio_s2m_profile prof{};
     int launches_this_run = 0;
@@ -121,6 +122,7 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->record_corr_iter = -1;
     c->kernel_variant = 0;
     c->profile = 0;
+    c->lookahead = -1;
 }
 
 static void lio_fill_consts(lio_s2m_handle* h)
@@ -154,7 +156,12 @@ extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
     lio_fill_consts(h);
     h->shard.axis = -1;
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (int i = 0; i <= LIO_MAX_ITERS; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
+    for (int i = 0; i < LIO_MAX_ITERS; ++i) {
+        HIPCHK(hipEventCreate(&h->ev_beg[i]));
+        HIPCHK(hipEventCreate(&h->ev_end[i]));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_chk[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipHostMalloc((void**)&h->h_active, sizeof(int) * LIO_MAX_ITERS, hipHostMallocDefault));
     HIPCHK(hipEventCreate(&h->ev_map[0]));
     HIPCHK(hipEventCreate(&h->ev_map[1]));
     h->ev_ok = true;
@@ -175,7 +182,10 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_rec_coeff, h->d_rec_nn, h->d_active };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) {
-        for (int i = 0; i <= LIO_MAX_ITERS; ++i) (void)hipEventDestroy(h->ev[i]);
+        for (int i = 0; i < LIO_MAX_ITERS; ++i) {
+            (void)hipEventDestroy(h->ev_beg[i]); (void)hipEventDestroy(h->ev_end[i]); (void)hipEventDestroy(h->ev_chk[i]);
+        }
+        if (h->h_active) (void)hipHostFree(h->h_active);
         (void)hipEventDestroy(h->ev_map[0]);
         (void)hipEventDestroy(h->ev_map[1]);
     }
@@ -419,6 +429,7 @@ static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_ou
     P.partials = h->d_partials;
     P.arrive = h->d_arrive;
     P.max_blk = h->max_blk;
+    P.n_active = h->d_active;
     P.sums_out = sums_out;
     const bool rec = h->cfg.record_corr_iter >= 0;
     P.rec_flag = rec ? h->d_rec_flag : nullptr;
@@ -432,7 +443,7 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     if (!h->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
     if (h->n_scans < 1 || !h->poses_set) return lio_fail(LIO_ERR_ARG, "batch_upload and batch_set_poses first");
     HIPCHK(hipSetDevice(h->cfg.device_id));
-    lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->c, h->stream);
+    lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->c, h->d_active, h->stream);
     h->launches_this_run = 0;
     h->ran = true;
     return LIO_OK;
@@ -445,12 +456,28 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
     LioIterParams P;
     lio_fill_params(h, P, nullptr);
     const bool prof = h->cfg.profile != 0;
-    if (prof) HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    // The GN loop (MO:1848-1859) runs ahead of the device by `lookahead`
+    // launches: after every launch the count of still-iterating scans is copied
+    // to pinned memory; launch i is only enqueued once the count after launch
+    // i-1-lookahead is known to be non-zero.  lookahead 0 never enqueues an
+    // empty launch; larger values keep the queue fed for small batches.
+    int look = h->cfg.lookahead;
+    if (look < 0) look = (h->total_pts >= 200000) ? 0 : 2;
+    int launched = 0;
     for (int it = 0; it < h->cfg.max_iters; ++it) {      // MO:1848
+        const int chk = it - 1 - look;
+        if (chk >= 0) {
+            HIPCHK(hipEventSynchronize(h->ev_chk[chk]));
+            if (h->h_active[chk] == 0) break;
+        }
+        if (prof) HIPCHK(hipEventRecord(h->ev_beg[it], h->stream));
         lio_launch_iterate(P, h->n_blocks, h->ppt, h->stream);
-        if (prof) HIPCHK(hipEventRecord(h->ev[it + 1], h->stream));
+        if (prof) HIPCHK(hipEventRecord(h->ev_end[it], h->stream));
+        HIPCHK(hipMemcpyAsync(&h->h_active[it], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->ev_chk[it], h->stream));
+        ++launched;
     }
-    h->launches_this_run = h->cfg.max_iters;
+    h->launches_this_run = launched;
     HIPCHK(hipGetLastError());
     return LIO_OK;
 }
@@ -474,7 +501,7 @@ extern "C" int lio_s2m_batch_iter_apply(lio_s2m_handle* h, const double* d_sums)
     if (!h || !d_sums) return lio_fail(LIO_ERR_ARG, "null argument");
     if (!h->ran) return lio_fail(LIO_ERR_ARG, "batch_begin first");
     HIPCHK(hipSetDevice(h->cfg.device_id));
-    lio_launch_apply(h->d_state, h->n_scans, d_sums, h->c, h->stream);
+    lio_launch_apply(h->d_state, h->n_scans, d_sums, h->c, h->d_active, h->stream);
     HIPCHK(hipGetLastError());
     return LIO_OK;
 }
@@ -483,11 +510,9 @@ extern "C" int lio_s2m_batch_n_active(lio_s2m_handle* h, int32_t* n_active)
 {
     if (!h || !n_active) return lio_fail(LIO_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device_id));
-    lio_launch_count_active(h->d_state, h->n_scans, h->d_active, h->stream);
-    int v = 0;
-    HIPCHK(hipMemcpyAsync(&v, h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&h->h_active[0], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    *n_active = v;
+    *n_active = h->h_active[0];
     return LIO_OK;
 }
 
@@ -532,10 +557,19 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
     }
     h->prof.point_iters = pit;
     h->prof.n_launches = h->launches_this_run;
-    if (h->cfg.profile && h->launches_this_run > 0 && h->launches_this_run <= LIO_MAX_ITERS) {
-        for (int i = 0; i < h->launches_this_run; ++i) {
+    for (int i = 0; i < LIO_MAX_ITERS; ++i) { h->prof.launch_ms[i] = 0.0f; h->prof.launch_active[i] = 0; }
+    for (int i = 0; i < h->launches_this_run && i < LIO_MAX_ITERS; ++i) {
+        // scans still iterating BEFORE launch i = those that took part in it
+        int act = 0;
+        for (int s = 0; s < h->n_scans; ++s) {
+            const LioScanState& st = h->h_state[s];
+            const int ran = st.status == 1 ? 0 : (st.status == 2 ? 1 : st.iter);
+            if (i < ran) ++act;
+        }
+        h->prof.launch_active[i] = act;
+        if (h->cfg.profile) {
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) != hipSuccess) ms = -1.0f;
+            if (hipEventElapsedTime(&ms, h->ev_beg[i], h->ev_end[i]) != hipSuccess) ms = -1.0f;
             h->prof.launch_ms[i] = ms;
         }
     }

@@ -1,0 +1,232 @@
+"""Closed-form pins of the CPU oracle (oracle/lio_oracle.c).
+
+The reference has no tests or golden vectors for this path (SURVEY 4 / 8c:
+"parity unpinned"), so every building block of the restatement is checked
+against an independent closed form: scipy rotations, numpy.linalg, brute force
+k-NN, finite differences.
+"""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+
+def test_get_transformation_matches_scipy_xyz_euler(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        r, p, y = rng.uniform(-np.pi, np.pi, 3)
+        t = rng.uniform(-100, 100, 3)
+        T = oracle.get_transformation(*t, r, p, y)
+        R = Rotation.from_euler("xyz", [r, p, y]).as_matrix()    # = Rz(yaw) Ry(pitch) Rx(roll)
+        np.testing.assert_allclose(T[:, :3], R, atol=3e-7)
+        np.testing.assert_array_equal(T[:, 3], t.astype(np.float32))
+
+
+def test_trig_modes_agree_to_one_ulp(oracle):
+    rng = np.random.default_rng(1)
+    diffs = 0
+    n = 2000
+    for _ in range(n):
+        r, p, y = rng.uniform(-np.pi, np.pi, 3).astype(np.float32)
+        a = oracle.get_transformation(0, 0, 0, r, p, y, trig_mode=0)
+        b = oracle.get_transformation(0, 0, 0, r, p, y, trig_mode=1)
+        np.testing.assert_allclose(a, b, atol=2.5e-7)
+        diffs += int(not np.array_equal(a, b))
+    # libm sinf/cosf are within one ulp of the correctly rounded value; the two
+    # definitions of the reference's `sin(float)` rarely differ in the last bit
+    assert diffs < 0.2 * n
+
+
+def test_knn_kdtree_equals_brute_force_including_ties(oracle):
+    rng = np.random.default_rng(2)
+    # half lattice points (many exact distance ties), half random
+    lattice = np.stack(np.meshgrid(*[np.arange(8, dtype=np.float32) * 0.5] * 3, indexing="ij"), -1).reshape(-1, 3)
+    pts = np.concatenate([lattice, lattice[:50], rng.uniform(0, 4, (700, 3)).astype(np.float32)])
+    q = np.concatenate([lattice[::7] + np.float32(0.25), rng.uniform(-1, 5, (300, 3)).astype(np.float32)])
+    ik, dk = oracle.knn5(pts, q, "kdtree")
+    ib, db = oracle.knn5(pts, q, "brute")
+    np.testing.assert_array_equal(ik, ib)
+    np.testing.assert_array_equal(dk, db)
+    # independent check: numpy fp32 distances with the same (d2, index) order
+    for j in range(0, len(q), 17):
+        d = pts - q[j]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        order = np.lexsort((np.arange(len(pts)), d2))[:5]
+        np.testing.assert_array_equal(ib[j], order)
+        np.testing.assert_array_equal(db[j], d2[order])
+    assert (np.diff(db, axis=1) >= 0).all()
+
+
+def test_knn_fewer_than_five_points(oracle):
+    pts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    idx, d2 = oracle.knn5(pts, np.array([[0.1, 0, 0]], np.float32), "kdtree")
+    assert list(idx[0][:3]) == [0, 1, 2] and list(idx[0][3:]) == [-1, -1]
+    assert np.isinf(d2[0][3:]).all()
+
+
+def test_plane_fit_matches_lstsq(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        d = rng.uniform(2, 40)
+        # 5 points near the plane n.x + d = 0
+        basis = np.linalg.svd(n[None, :])[2][1:]
+        uv = rng.uniform(-0.5, 0.5, (5, 2))
+        P = (uv @ basis) - d * n + rng.normal(0, 0.01, (5, 3))
+        x = oracle.plane_fit(P.astype(np.float32))
+        ref = np.linalg.lstsq(P.astype(np.float32).astype(np.float64), -np.ones(5), rcond=None)[0]
+        np.testing.assert_allclose(x, ref, rtol=2e-3, atol=2e-5)
+
+
+def test_plane_fit_rank_deficient_is_finite_and_minimum_norm_like(oracle):
+    # five collinear points: Eigen zeroes the non-pivot coefficients instead of dividing by ~0
+    t = np.linspace(0, 1, 5, dtype=np.float32)
+    P = np.stack([1 + t, 2 + 2 * t, 3 + 3 * t], 1).astype(np.float32)
+    x = oracle.plane_fit(P)
+    assert np.isfinite(x).all()
+    # five identical points: rank 1
+    x = oracle.plane_fit(np.tile(np.array([[1, 2, 3]], np.float32), (5, 1)))
+    assert np.isfinite(x).all()
+    r = np.tile(np.array([[1, 2, 3]], np.float32), (5, 1)) @ x + 1
+    np.testing.assert_allclose(r, 0, atol=1e-5)
+    # all zeros: Eigen's zero-pivot test is `norm^2 < 0`, so nonzeroPivots() stays 3 and the
+    # solve divides by zero -- the restatement keeps that; the NaN plane is then rejected
+    # by `s > 0.1` (MO:1679) instead of being special-cased.
+    assert not np.isfinite(oracle.plane_fit(np.zeros((5, 3), np.float32))).any()
+    cfg = oracle.default_config(knn_mode=0)
+    flag, coeff, nn = oracle.surf_optimization(cfg, np.zeros(6, np.float32), np.zeros((3, 3), np.float32),
+                                               np.zeros((6, 3), np.float32))
+    assert not flag.any() and (nn[:, 4] >= 0).all()
+
+
+def test_qr_solve_general_rhs(oracle):
+    rng = np.random.default_rng(4)
+    for _ in range(100):
+        A = rng.normal(size=(5, 3)).astype(np.float32)
+        b = rng.normal(size=5).astype(np.float32)
+        x = oracle.qr_solve_5x3(A, b)
+        ref = np.linalg.lstsq(A.astype(np.float64), b.astype(np.float64), rcond=None)[0]
+        np.testing.assert_allclose(x, ref, rtol=1e-4, atol=1e-5)
+
+
+def _spd6(rng, scale=1.0):
+    J = rng.normal(size=(200, 6)) * scale
+    return (J.T @ J).astype(np.float32)
+
+
+def test_solve6_eigen6_inv6_match_numpy(oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(100):
+        A = _spd6(rng, rng.uniform(0.1, 30))
+        b = rng.normal(size=6).astype(np.float32)
+        x, ok = oracle.solve6(A, b)
+        assert ok == 1
+        np.testing.assert_allclose(x, np.linalg.solve(A.astype(np.float64), b), rtol=2e-3, atol=1e-6)
+        w, v = oracle.eigen6(A)
+        wr, vr = np.linalg.eigh(A.astype(np.float64))
+        np.testing.assert_allclose(w, wr[::-1], rtol=1e-4, atol=1e-3 * abs(wr).max())
+        assert (np.diff(w) <= 0).all()                       # descending
+        for i in range(6):                                   # eigenvectors are ROWS
+            np.testing.assert_allclose(A.astype(np.float64) @ v[i], w[i] * v[i], atol=2e-3 * abs(wr).max())
+        inv, ok = oracle.inv6(v)
+        assert ok == 1
+        np.testing.assert_allclose(inv @ v, np.eye(6), atol=1e-5)
+    sing = np.diag([4, 3, 2, 1, 1, 1e-8]).astype(np.float32)       # singular to fp32: X = 0 (cv::solve returns false)
+    x, ok = oracle.solve6(sing, np.ones(6, np.float32))
+    assert ok == 0 and not x.any()
+    inv, ok = oracle.inv6(sing)
+    assert ok == 0 and not inv.any()
+
+
+def _residual(pose, p, n):
+    R = Rotation.from_euler("xyz", pose[:3]).as_matrix()
+    return n[:3] @ (R @ p + pose[3:6]) + n[3]
+
+
+def test_jacobian_exact_mode_matches_finite_differences(oracle):
+    rng = np.random.default_rng(6)
+    for _ in range(200):
+        pose = np.concatenate([rng.uniform(-0.6, 0.6, 3), rng.uniform(-5, 5, 3)])
+        p = rng.uniform(-30, 30, 3)
+        n = np.concatenate([rng.normal(size=3), [rng.normal()]])
+        row, rhs = oracle.jacobian_row(pose, p, n, jacobian_mode=1)
+        eps = 1e-6
+        fd = np.zeros(6)
+        for k in range(6):
+            d = np.zeros(6); d[k] = eps
+            fd[k] = (_residual(pose + d, p, n) - _residual(pose - d, p, n)) / (2 * eps)
+        np.testing.assert_allclose(row, fd, rtol=2e-4, atol=2e-4)
+        assert rhs == -np.float32(n[3])
+
+
+def test_jacobian_reference_mode_carries_the_MO1764_term(oracle):
+    """MO:1764 has sin(yaw)*sin(pitch)*sin(roll)*y where the derivative has
+    sin(yaw)*cos(pitch)*sin(roll)*y: the default mode must differ
+    from the exact one by exactly that term on the pitch column."""
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        pose = np.concatenate([rng.uniform(-0.6, 0.6, 3), rng.uniform(-5, 5, 3)])
+        p = rng.uniform(-30, 30, 3)
+        n = np.concatenate([rng.normal(size=3), [rng.normal()]])
+        ref, _ = oracle.jacobian_row(pose, p, n, jacobian_mode=0)
+        ex, _ = oracle.jacobian_row(pose, p, n, jacobian_mode=1)
+        roll, pitch, yaw = pose[:3]
+        term = np.sin(yaw) * np.sin(roll) * (np.sin(pitch) - np.cos(pitch)) * p[1] * n[1]
+        np.testing.assert_allclose(ref[1] - ex[1], term, atol=3e-4 * (1 + abs(term)))
+        np.testing.assert_array_equal(np.delete(ref, 1), np.delete(ex, 1))
+
+
+def test_jacobian_reference_mode_literal_transcription(oracle):
+    """Third, independent transcription of MO:1760-1769 (float64 numpy)."""
+    rng = np.random.default_rng(8)
+    for _ in range(100):
+        pose = np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(-5, 5, 3)])
+        x, y, z = rng.uniform(-30, 30, 3)
+        cx, cy, cz, ci = rng.normal(size=4)
+        srx, crx = np.sin(pose[2]), np.cos(pose[2])
+        sry, cry = np.sin(pose[1]), np.cos(pose[1])
+        srz, crz = np.sin(pose[0]), np.cos(pose[0])
+        arx = (-srx*cry*x - (srx*sry*srz + crx*crz)*y + (crx*srz - srx*sry*crz)*z)*cx \
+            + (crx*cry*x - (srx*crz - crx*sry*srz)*y + (crx*sry*crz + srx*srz)*z)*cy
+        ary = (-crx*sry*x + crx*cry*srz*y + crx*cry*crz*z)*cx \
+            + (-srx*sry*x + srx*sry*srz*y + srx*cry*crz*z)*cy \
+            + (-cry*x - sry*srz*y - sry*crz*z)*cz
+        arz = ((crx*sry*crz + srx*srz)*y + (srx*crz - crx*sry*srz)*z)*cx \
+            + ((-crx*srz + srx*sry*crz)*y + (-srx*sry*srz - crx*crz)*z)*cy \
+            + (cry*crz*y - cry*srz*z)*cz
+        row, rhs = oracle.jacobian_row(pose, [x, y, z], [cx, cy, cz, ci], jacobian_mode=0)
+        np.testing.assert_allclose(row, [arz, ary, arx, cx, cy, cz], rtol=3e-5, atol=3e-4)
+        assert rhs == -np.float32(ci)
+
+
+def test_transform_update_slerp_and_clamps(oracle):
+    from scipy.spatial.transform import Slerp
+    pose = np.array([0.10, -0.05, 1.0, 3.0, 4.0, 9.0], np.float32)
+    out = oracle.transform_update(pose, imu_available=1, imu_type=1, imu_roll_init=0.2, imu_pitch_init=0.1,
+                                  imu_rpy_weight=0.25, rotation_tollerance=1000.0, z_tollerance=5.0)
+    # single-axis slerp is linear in the angle
+    np.testing.assert_allclose(out[0], 0.10 + 0.25 * (0.2 - 0.10), atol=1e-6)
+    np.testing.assert_allclose(out[1], -0.05 + 0.25 * (0.1 + 0.05), atol=1e-6)
+    assert out[2] == pose[2] and out[5] == np.float32(5.0)
+    sl = Slerp([0, 1], Rotation.from_euler("xyz", [[0.10, 0, 0], [0.2, 0, 0]]))
+    np.testing.assert_allclose(out[0], sl([0.25]).as_euler("xyz")[0][0], atol=1e-6)
+    # |imuPitchInit| >= 1.4 disables the blend (MO:1871); 6-axis IMU (imuType 0) too
+    out2 = oracle.transform_update(pose, 1, 1, 0.2, 1.45, 0.25, 0.08, 1000.0)
+    assert out2[0] == np.float32(0.08) and out2[1] == pose[1]
+    out3 = oracle.transform_update(pose, 1, 0, 0.2, 0.1, 0.25)
+    np.testing.assert_array_equal(out3, pose)
+
+
+def test_curvature_formula(oracle):
+    rng = np.random.default_rng(9)
+    r = rng.uniform(1, 80, 500).astype(np.float32)
+    curv, picked, label = oracle.calculate_smoothness(r)
+    ref = np.zeros_like(r)
+    for i in range(5, len(r) - 5):
+        d = r[i-5] + r[i-4] + r[i-3] + r[i-2] + r[i-1] - r[i] * np.float32(10) \
+            + r[i+1] + r[i+2] + r[i+3] + r[i+4] + r[i+5]
+        ref[i] = d * d
+    np.testing.assert_array_equal(curv, ref)          # numpy fp32 scalars, same order: bit-exact
+    assert (picked[5:-5] == 0).all() and (label[5:-5] == 0).all()
+    assert (picked[:5] == -1).all() and (picked[-5:] == -1).all()     # untouched margins, FE:84
+    c2, _, _ = oracle.calculate_smoothness(r[:10])                     # n < 11: empty loop
+    assert not c2.any()
