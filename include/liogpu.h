@@ -66,6 +66,9 @@ typedef struct lio_s2m_config {
     int32_t profile;         /* 1 = bracket every GN-iteration launch with HIP events      */
     int32_t lookahead;       /* GN launches enqueued ahead of the convergence check;
                                 0 = never enqueue an empty launch, -1 = auto               */
+    int32_t use_lds;         /* 1 = stage the workgroup's map region through LDS (default) */
+    int32_t sort_scan;       /* 1 = re-order scans by 4 m tiles at upload (default);
+                                results are reported in the caller's order either way      */
 } lio_s2m_config;
 
 /* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in

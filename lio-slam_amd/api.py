@@ -30,7 +30,7 @@ class S2MConfig(C.Structure):
         ("min_scan_pts", C.c_int32), ("jacobian_mode", C.c_int32), ("force_all_iters", C.c_int32),
         ("device_id", C.c_int32), ("cell_size", C.c_float), ("max_batch", C.c_int32),
         ("max_scan_pts", C.c_int32), ("record_corr_iter", C.c_int32), ("kernel_variant", C.c_int32),
-        ("profile", C.c_int32), ("lookahead", C.c_int32),
+        ("profile", C.c_int32), ("lookahead", C.c_int32), ("use_lds", C.c_int32), ("sort_scan", C.c_int32),
     ]
 
 

@@ -14,6 +14,7 @@ struct LioIterParams {
     const float* sx;               // batch scan SoA (all scans concatenated)
     const float* sy;
     const float* sz;
+    const int* perm;               // sorted slot -> caller's point index (batch-global); may be null
     LioScanState* state;
     const LioBlockDesc* blocks;
     double* partials;              // [scan][max_blk][LIO_SUMS]
@@ -35,6 +36,11 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
 int  lio_scan_tiles(int n_cells);
 void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c,
                            int* n_active, hipStream_t s);
-void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, hipStream_t s);
+void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s);
 void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
                       int* n_active, hipStream_t s);
+void lio_launch_scan_tile_sort(const void* stage, size_t stride, int total_pts,
+                               const LioBlockDesc* prep_blocks, int n_prep_blocks,
+                               const LioScanState* st, const LioScanTiles* tiles, int n_keys,
+                               int* key_of, int* key_count, int* key_start, int* tile_sums,
+                               int* tmp_idx, int* perm, float* x, float* y, float* z, hipStream_t s);

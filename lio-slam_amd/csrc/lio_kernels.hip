@@ -178,6 +178,83 @@ __global__ void k_map_scatter(const float* __restrict__ x, const float* __restri
     sorted[cell_start[c] + slot] = make_float4(x[i], y[i], z[i], __int_as_float(i));
 }
 
+// ------------------------------------------------- scan tile sort (upload)
+// The scan (laserCloudSurfLastDS, MO:138) is re-ordered once per upload so that
+// the 256*PPT consecutive points of an association workgroup lie in a compact
+// blob: points are bucketed by 4 m tiles of a scan-local grid (x-fastest tile
+// id, scans in batch order), ties inside a tile keep the caller's order, so the
+// order -- and with it every reduction tree -- is deterministic.
+LIO_DEV int lio_tile_coord(float v, float origin, float inv_tile, int n)
+{
+    float c = floorf((v - origin) * inv_tile);
+    c = fminf(fmaxf(c, 0.0f), (float)(n - 1));      // NaN -> 0
+    return (int)c;
+}
+
+__global__ __launch_bounds__(256) void k_scan_tile_keys(const unsigned char* __restrict__ stage, size_t stride,
+                                                        const LioBlockDesc* __restrict__ prep_blocks,
+                                                        const LioScanState* __restrict__ st,
+                                                        const LioScanTiles* __restrict__ tiles,
+                                                        int* __restrict__ key_of, int* __restrict__ key_count)
+{
+    const LioBlockDesc bd = prep_blocks[blockIdx.x];
+    const int li = bd.first + (int)threadIdx.x;
+    if (li >= st[bd.scan].n_pts) return;
+    const int gi = st[bd.scan].offset + li;
+    const LioScanTiles t = tiles[bd.scan];
+    const float* p = reinterpret_cast<const float*>(stage + (size_t)gi * stride);
+    const int tx = lio_tile_coord(p[0], t.ox, t.inv_tile, t.ntx);
+    const int ty = lio_tile_coord(p[1], t.oy, t.inv_tile, t.nty);
+    const int tz = lio_tile_coord(p[2], t.oz, t.inv_tile, t.ntz);
+    const int key = t.key_offset + (tz * t.nty + ty) * t.ntx + tx;
+    key_of[gi] = key;
+    atomicAdd(&key_count[key], 1);
+}
+
+__global__ void k_scan_tile_scatter(const int* __restrict__ key_of, int n, const int* __restrict__ key_start,
+                                    int* __restrict__ key_fill, int* __restrict__ tmp_idx)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = key_of[i];
+    tmp_idx[key_start[k] + atomicAdd(&key_fill[k], 1)] = i;
+}
+
+// one wave per tile: order the tile's points by their caller index (rank sort in LDS)
+#define LIO_TILE_CAP 1024
+__global__ __launch_bounds__(256) void k_scan_tile_ranksort(const int* __restrict__ key_start, int n_keys,
+                                                            const int* __restrict__ tmp_idx, int* __restrict__ perm)
+{
+    __shared__ int s_el[4][LIO_TILE_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 4 + wave;
+    if (k >= n_keys) return;
+    const int b = key_start[k], n = key_start[k + 1] - b;
+    if (n <= 0) return;
+    if (n > LIO_TILE_CAP) {                          // oversized tile: keep the scatter order
+        for (int j = lane; j < n; j += 64) perm[b + j] = tmp_idx[b + j];
+        return;
+    }
+    for (int j = lane; j < n; j += 64) s_el[wave][j] = tmp_idx[b + j];
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < n; j += 64) {
+        const int v = s_el[wave][j];
+        int rank = 0;
+        for (int i = 0; i < n; ++i) rank += (s_el[wave][i] < v) ? 1 : 0;
+        perm[b + rank] = v;
+    }
+}
+
+__global__ void k_scan_gather_sorted(const unsigned char* __restrict__ stage, size_t stride, int n,
+                                     const int* __restrict__ perm,
+                                     float* __restrict__ x, float* __restrict__ y, float* __restrict__ z)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float* p = reinterpret_cast<const float*>(stage + (size_t)perm[j] * stride);
+    x[j] = p[0]; y[j] = p[1]; z[j] = p[2];
+}
+
 // -------------------------------------------------------------- GN iterate
 // top-5 keys: (bits(d2) << 32) | original index -- d2 >= 0, so the unsigned
 // 64-bit order is the lexicographic (d2, index) order of the exact k-NN
@@ -329,13 +406,100 @@ __global__ void k_s2m_init_state(LioScanState* __restrict__ st, int n_scans,
     if (enough) atomicAdd(n_active, 1);
 }
 
+// ---- candidate scan, global-memory form -----------------------------------
+// 27-cell neighbourhood = 9 (y,z) rows of three x-adjacent cells = 9 contiguous
+// runs of the cell-sorted map.  The 18 run bounds are fetched first (one memory
+// latency), then the runs are walked four candidates at a time so that four
+// 16-byte loads are in flight per lane.
+LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
+                            int cx, int cy, int cz, LioTop5& top)
+{
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    if (x0 > x1) return;
+    int beg[9], end[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        const bool in = (z >= 0) && (z < g.nz) && (y >= 0) && (y < g.ny);
+        const int row = in ? (z * g.ny + y) * g.nx : 0;
+        const int b = P.cell_start[row + x0];
+        const int e = P.cell_start[row + x1 + 1];
+        beg[r] = b;
+        end[r] = in ? e : b;
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        for (int j = beg[r]; j < end[r]; j += 4) {
+            float4 m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) m[u] = P.map_sorted[min(j + u, end[r] - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j + u < end[r]) {
+                    const float d2 = lio_sqdist(m[u].x, m[u].y, m[u].z, qx, qy, qz);
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(m[u].w);
+                    lio_top5_insert(top, key);
+                }
+            }
+        }
+    }
+}
+
+// ---- candidate scan, LDS form ---------------------------------------------
+// s_pts holds the map points of the workgroup's cell region (rows of the
+// region are contiguous runs), s_cell the run offsets of every cell of the
+// region: rx+1 entries per (y,z) row.
+LIO_DEV void lio_knn_lds(const float4* s_pts, const int* s_cell, int rx1, int ry,
+                         int rx0, int ry0, int rz0, int ry1, int rz1, int nx,
+                         float qx, float qy, float qz, int cx, int cy, int cz, LioTop5& top)
+{
+    const int xa = max(cx - 1, 0), xb = min(cx + 1, nx - 1);
+    if (xa > xb) return;
+#pragma unroll 1
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int z = cz + dz;
+        if (z < rz0 || z > rz1) continue;
+#pragma unroll 1
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = cy + dy;
+            if (y < ry0 || y > ry1) continue;
+            const int r = (z - rz0) * ry + (y - ry0);
+            const int b = s_cell[r * rx1 + (xa - rx0)];
+            const int e = s_cell[r * rx1 + (xb + 1 - rx0)];
+            for (int j = b; j < e; ++j) {
+                const float4 m = s_pts[j];
+                const float d2 = lio_sqdist(m.x, m.y, m.z, qx, qy, qz);
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(m.w);
+                lio_top5_insert(top, key);
+            }
+        }
+    }
+}
+
+#define LIO_LDS_PTS   2048     // staged map points per workgroup (32 KiB)
+#define LIO_LDS_CELLS 1536     // staged run offsets (6 KiB)
+#define LIO_LDS_ROWS  256      // (y,z) rows of a region
+
 // One thread = one scan point (x PPT points, strided by the workgroup size).
-template <int PPT>
+// STAGE: the workgroup's points are spatially sorted at upload, so their
+// 27-cell neighbourhoods overlap heavily: the union region of the map is staged
+// through LDS once (coalesced 16-byte loads) and every lane scans its
+// candidates from LDS.  Regions that do not fit fall back to the global form;
+// both forms visit the same candidate set, so results are identical.
+template <int PPT, bool STAGE>
 __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
 {
     __shared__ double s_part[LIO_BLOCK / 64][28];
     __shared__ double s_sum[28];
     __shared__ LioSolveWs s_ws;
+    __shared__ __attribute__((aligned(16))) float4 s_pts[STAGE ? LIO_LDS_PTS : 1];
+    __shared__ int s_cell[STAGE ? LIO_LDS_CELLS : 1];
+    __shared__ int s_row_beg[STAGE ? LIO_LDS_ROWS : 1];
+    __shared__ int s_row_off[STAGE ? LIO_LDS_ROWS + 1 : 1];
+    __shared__ int s_box[8];
+    __shared__ int s_scan4[4];
 
     const LioBlockDesc bd = P.blocks[blockIdx.x];
     LioScanState* st = &P.state[bd.scan];
@@ -351,6 +515,107 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
     const int base = st->offset;
     const bool record = (P.rec_flag != nullptr) && (st->iter == P.c.record_iter);
     const LioGrid g = P.grid;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // ---- phase A: transform (pointAssociateToMap, MO:841-847), cells, ownership
+    float px[PPT], py[PPT], pz[PPT], qx[PPT], qy[PPT], qz[PPT];
+    int cx[PPT], cy[PPT], cz[PPT];
+    bool act[PPT], inr[PPT];
+    int bmn[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, bmx[3] = { -0x7fffffff, -0x7fffffff, -0x7fffffff };
+#pragma unroll
+    for (int pp = 0; pp < PPT; ++pp) {
+        const int li = bd.first + pp * LIO_BLOCK + (int)threadIdx.x;
+        inr[pp] = li < n_pts;
+        const int gi = base + (inr[pp] ? li : 0);
+        px[pp] = P.sx[gi]; py[pp] = P.sy[gi]; pz[pp] = P.sz[gi];     // coalesced SoA
+        qx[pp] = T[0] * px[pp] + T[1] * py[pp] + T[2]  * pz[pp] + T[3];
+        qy[pp] = T[4] * px[pp] + T[5] * py[pp] + T[6]  * pz[pp] + T[7];
+        qz[pp] = T[8] * px[pp] + T[9] * py[pp] + T[10] * pz[pp] + T[11];
+        bool a = inr[pp];
+        if (P.shard.axis >= 0) {                                     // owner-computes (multi-GPU)
+            const float qa = P.shard.axis == 0 ? qx[pp] : (P.shard.axis == 1 ? qy[pp] : qz[pp]);
+            int gc = lio_cell_coord(qa, P.shard.gorigin, P.shard.inv_cell, P.shard.gdim);
+            gc = min(max(gc, 0), P.shard.gdim - 1);
+            a = a && gc >= P.shard.lo && gc < P.shard.hi;
+        }
+        cx[pp] = lio_cell_coord(qx[pp], g.ox, g.inv_cell, g.nx);
+        cy[pp] = lio_cell_coord(qy[pp], g.oy, g.inv_cell, g.ny);
+        cz[pp] = lio_cell_coord(qz[pp], g.oz, g.inv_cell, g.nz);
+        // a point whose 27 cells all lie outside the grid has no candidates at all
+        a = a && cx[pp] >= -1 && cx[pp] <= g.nx && cy[pp] >= -1 && cy[pp] <= g.ny && cz[pp] >= -1 && cz[pp] <= g.nz;
+        act[pp] = a;
+        if (STAGE && a) {
+            bmn[0] = min(bmn[0], cx[pp]); bmx[0] = max(bmx[0], cx[pp]);
+            bmn[1] = min(bmn[1], cy[pp]); bmx[1] = max(bmx[1], cy[pp]);
+            bmn[2] = min(bmn[2], cz[pp]); bmx[2] = max(bmx[2], cz[pp]);
+        }
+    }
+
+    // ---- phase B: stage the union cell region of the workgroup through LDS
+    bool staged = false;
+    int rx0 = 0, ry0 = 0, rz0 = 0, rx1c = 0, ry1 = -1, rz1 = -1, rxn1 = 1, ryn = 1;
+    if (STAGE) {
+        if (threadIdx.x < 3) { s_box[threadIdx.x] = 0x7fffffff; s_box[3 + threadIdx.x] = -0x7fffffff; }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                bmn[a] = min(bmn[a], __shfl_xor(bmn[a], off));
+                bmx[a] = max(bmx[a], __shfl_xor(bmx[a], off));
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { atomicMin(&s_box[a], bmn[a]); atomicMax(&s_box[3 + a], bmx[a]); }
+        }
+        __syncthreads();
+        rx0 = max(s_box[0] - 1, 0); rx1c = min(s_box[3] + 1, g.nx - 1);
+        ry0 = max(s_box[1] - 1, 0); ry1 = min(s_box[4] + 1, g.ny - 1);
+        rz0 = max(s_box[2] - 1, 0); rz1 = min(s_box[5] + 1, g.nz - 1);
+        const bool any = s_box[0] != 0x7fffffff && rx0 <= rx1c && ry0 <= ry1 && rz0 <= rz1;
+        rxn1 = rx1c - rx0 + 2;                      // run offsets per row (cells + 1)
+        ryn = ry1 - ry0 + 1;
+        const int rzn = rz1 - rz0 + 1;
+        const int n_rows = ryn * rzn;
+        bool fits = any && n_rows <= LIO_LDS_ROWS && n_rows * rxn1 <= LIO_LDS_CELLS;
+        if (fits) {                                  // workgroup-uniform
+            // run of every (y,z) row of the region, exclusive scan of the run lengths
+            int cnt = 0;
+            if ((int)threadIdx.x < n_rows) {
+                const int z = rz0 + (int)threadIdx.x / ryn, y = ry0 + (int)threadIdx.x % ryn;
+                const int row = (z * g.ny + y) * g.nx;
+                const int b = P.cell_start[row + rx0];
+                cnt = P.cell_start[row + rx1c + 1] - b;
+                s_row_beg[threadIdx.x] = b;
+            }
+            int total;
+            const int off = lio_block_exclusive_scan(cnt, &total, s_scan4);
+            if ((int)threadIdx.x < n_rows) s_row_off[threadIdx.x] = off;
+            if ((int)threadIdx.x == n_rows) s_row_off[n_rows] = total;
+            fits = total <= LIO_LDS_PTS;
+            __syncthreads();
+            if (fits) {
+                for (int i = threadIdx.x; i < n_rows * rxn1; i += LIO_BLOCK) {
+                    const int r = i / rxn1, xi = i - r * rxn1;
+                    const int z = rz0 + r / ryn, y = ry0 + r % ryn;
+                    const int row = (z * g.ny + y) * g.nx;
+                    s_cell[i] = s_row_off[r] + (P.cell_start[row + rx0 + xi] - s_row_beg[r]);
+                }
+                for (int i = threadIdx.x; i < total; i += LIO_BLOCK) {
+                    // row of staged slot i: last r with s_row_off[r] <= i
+                    int lo = 0, hi = n_rows - 1;
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (s_row_off[mid] <= i) lo = mid; else hi = mid - 1;
+                    }
+                    s_pts[i] = P.map_sorted[s_row_beg[lo] + (i - s_row_off[lo])];
+                }
+                staged = true;
+            }
+            __syncthreads();
+        }
+    }
 
     double acc[28];
 #pragma unroll
@@ -358,57 +623,20 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
 
 #pragma unroll 1
     for (int pp = 0; pp < PPT; ++pp) {
-        const int li = bd.first + pp * LIO_BLOCK + (int)threadIdx.x;
-        const bool in_range = li < n_pts;
-        const int gi = base + (in_range ? li : 0);
-        const float px = P.sx[gi], py = P.sy[gi], pz = P.sz[gi];     // coalesced SoA
-
-        // pointAssociateToMap, MO:841-847
-        const float qx = T[0] * px + T[1] * py + T[2]  * pz + T[3];
-        const float qy = T[4] * px + T[5] * py + T[6]  * pz + T[7];
-        const float qz = T[8] * px + T[9] * py + T[10] * pz + T[11];
-
-        bool active = in_range;
-        if (P.shard.axis >= 0) {                                     // owner-computes (multi-GPU)
-            const float qa = P.shard.axis == 0 ? qx : (P.shard.axis == 1 ? qy : qz);
-            int gc = lio_cell_coord(qa, P.shard.gorigin, P.shard.inv_cell, P.shard.gdim);
-            gc = min(max(gc, 0), P.shard.gdim - 1);
-            active = active && gc >= P.shard.lo && gc < P.shard.hi;
-        }
-
         // ---- exact 5-NN over the 27-cell neighbourhood (MO:1631) ----
         const unsigned long long sentinel =
             ((unsigned long long)__float_as_uint(P.c.max_sq_dist) << 32) | 0x7fffffffull;
         LioTop5 top = { sentinel, sentinel, sentinel, sentinel, sentinel };
-        const int cx = lio_cell_coord(qx, g.ox, g.inv_cell, g.nx);
-        const int cy = lio_cell_coord(qy, g.oy, g.inv_cell, g.ny);
-        const int cz = lio_cell_coord(qz, g.oz, g.inv_cell, g.nz);
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-        if (active && x0 <= x1) {
-#pragma unroll 1
-            for (int dz = -1; dz <= 1; ++dz) {
-                const int z = cz + dz;
-                if (z < 0 || z >= g.nz) continue;
-#pragma unroll 1
-                for (int dy = -1; dy <= 1; ++dy) {
-                    const int y = cy + dy;
-                    if (y < 0 || y >= g.ny) continue;
-                    const int row = (z * g.ny + y) * g.nx;
-                    const int beg = P.cell_start[row + x0];
-                    const int end = P.cell_start[row + x1 + 1];
-                    for (int j = beg; j < end; ++j) {
-                        const float4 m = P.map_sorted[j];
-                        const float d2 = lio_sqdist(m.x, m.y, m.z, qx, qy, qz);
-                        const unsigned long long key =
-                            ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(m.w);
-                        lio_top5_insert(top, key);
-                    }
-                }
-            }
+        if (act[pp]) {
+            if (STAGE && staged)
+                lio_knn_lds(s_pts, s_cell, rxn1, ryn, rx0, ry0, rz0, ry1, rz1, g.nx,
+                            qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], top);
+            else
+                lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], top);
         }
         // gate MO:1641: pointSearchSqDis[4] < 1.0
         const float d4 = __uint_as_float((unsigned)(top.k4 >> 32));
-        bool ok = active && (d4 < P.c.max_sq_dist);
+        const bool ok = act[pp] && (d4 < P.c.max_sq_dist);
 
         int nn[5] = { (int)(unsigned)top.k0, (int)(unsigned)top.k1, (int)(unsigned)top.k2,
                       (int)(unsigned)top.k3, (int)(unsigned)top.k4 };
@@ -419,8 +647,7 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
             float a[5][3], m[5][3];
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                const int id = nn[j];
-                const float4 mp = P.map_xyz4[id];
+                const float4 mp = P.map_xyz4[nn[j]];
                 m[j][0] = a[j][0] = mp.x;
                 m[j][1] = a[j][1] = mp.y;
                 m[j][2] = a[j][2] = mp.z;
@@ -437,24 +664,27 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
                 if ((double)v > P.c.plane_tol) planeValid = false;
             }
             if (planeValid) {
-                const float pd2 = pa * qx + pb * qy + pc * qz + pd;   // MO:1669
-                const float r2 = px * px + py * py + pz * pz;
+                const float pd2 = pa * qx[pp] + pb * qy[pp] + pc * qz[pp] + pd;   // MO:1669
+                const float r2 = px[pp] * px[pp] + py[pp] * py[pp] + pz[pp] * pz[pp];
                 // MO:1671-1672 (product, quotient and difference in double)
                 const float s = (float)(1 - P.c.weight * (double)fabsf(pd2) / (double)sqrtf(sqrtf(r2)));
                 cxx = s * pa; cyy = s * pb; czz = s * pc; cww = s * pd2;   // MO:1674-1677
                 accept = (double)s > P.c.min_s;                       // MO:1679
             }
         }
-        if (record && in_range) {
-            P.rec_flag[gi] = accept ? 1 : 0;
-            reinterpret_cast<float4*>(P.rec_coeff)[gi] = make_float4(cxx, cyy, czz, cww);
+        if (record && inr[pp]) {
+            // the record is kept in the CALLER's point order
+            const int li = bd.first + pp * LIO_BLOCK + (int)threadIdx.x;
+            const int oi = P.perm ? P.perm[base + li] : base + li;
+            P.rec_flag[oi] = accept ? 1 : 0;
+            reinterpret_cast<float4*>(P.rec_coeff)[oi] = make_float4(cxx, cyy, czz, cww);
 #pragma unroll
-            for (int j = 0; j < 5; ++j) P.rec_nn[(size_t)gi * 5 + j] = ok ? nn[j] : -1;
+            for (int j = 0; j < 5; ++j) P.rec_nn[(size_t)oi * 5 + j] = ok ? nn[j] : -1;
         }
         if (accept) {
             // MO:1735-1783: row of matA/matB, outer products accumulated in double
             float row[6], rhs;
-            lio_jacobian_row(tr, px, py, pz, cxx, cyy, czz, cww, P.c.jac_exact, row, rhs);
+            lio_jacobian_row(tr, px[pp], py[pp], pz[pp], cxx, cyy, czz, cww, P.c.jac_exact, row, rhs);
             int p = 0;
 #pragma unroll
             for (int a2 = 0; a2 < 6; ++a2)
@@ -467,7 +697,6 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
     }
 
     // ---- workgroup reduction: wave butterfly -> LDS -> fixed-order sum ----
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 28; ++k) {
         const double v = lio_wave_sum(acc[k]);
@@ -560,13 +789,22 @@ void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, co
     hipLaunchKernelGGL(k_s2m_init_state, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, poses, c, n_active);
 }
 
-void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, hipStream_t s)
+void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s)
 {
     if (n_blocks <= 0) return;
-    switch (ppt) {
-    case 1: hipLaunchKernelGGL(k_s2m_iterate<1>, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, P); break;
-    case 2: hipLaunchKernelGGL(k_s2m_iterate<2>, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, P); break;
-    default: hipLaunchKernelGGL(k_s2m_iterate<4>, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, P); break;
+    const dim3 gr(n_blocks), bl(LIO_BLOCK);
+    if (stage) {
+        switch (ppt) {
+        case 1: hipLaunchKernelGGL((k_s2m_iterate<1, true>), gr, bl, 0, s, P); break;
+        case 2: hipLaunchKernelGGL((k_s2m_iterate<2, true>), gr, bl, 0, s, P); break;
+        default: hipLaunchKernelGGL((k_s2m_iterate<4, true>), gr, bl, 0, s, P); break;
+        }
+    } else {
+        switch (ppt) {
+        case 1: hipLaunchKernelGGL((k_s2m_iterate<1, false>), gr, bl, 0, s, P); break;
+        case 2: hipLaunchKernelGGL((k_s2m_iterate<2, false>), gr, bl, 0, s, P); break;
+        default: hipLaunchKernelGGL((k_s2m_iterate<4, false>), gr, bl, 0, s, P); break;
+        }
     }
 }
 
@@ -574,4 +812,26 @@ void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const L
                       int* n_active, hipStream_t s)
 {
     hipLaunchKernelGGL(k_s2m_apply, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, sums, c, n_active);
+}
+
+void lio_launch_scan_tile_sort(const void* stage, size_t stride, int total_pts,
+                               const LioBlockDesc* prep_blocks, int n_prep_blocks,
+                               const LioScanState* st, const LioScanTiles* tiles, int n_keys,
+                               int* key_of, int* key_count, int* key_start, int* tile_sums,
+                               int* tmp_idx, int* perm, float* x, float* y, float* z, hipStream_t s)
+{
+    if (total_pts <= 0 || n_prep_blocks <= 0) return;
+    (void)hipMemsetAsync(key_count, 0, sizeof(int) * (size_t)n_keys, s);
+    hipLaunchKernelGGL(k_scan_tile_keys, dim3(n_prep_blocks), dim3(256), 0, s,
+                       (const unsigned char*)stage, stride, prep_blocks, st, tiles, key_of, key_count);
+    const int n_tiles = (n_keys + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, s, key_count, n_keys, tile_sums);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(256), 0, s, tile_sums, n_tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_tiles), dim3(256), 0, s, key_count, n_keys, tile_sums, key_start);
+    (void)hipMemsetAsync(key_count, 0, sizeof(int) * (size_t)n_keys, s);
+    const int nb = (total_pts + 255) / 256;
+    hipLaunchKernelGGL(k_scan_tile_scatter, dim3(nb), dim3(256), 0, s, key_of, total_pts, key_start, key_count, tmp_idx);
+    hipLaunchKernelGGL(k_scan_tile_ranksort, dim3((n_keys + 3) / 4), dim3(256), 0, s, key_start, n_keys, tmp_idx, perm);
+    hipLaunchKernelGGL(k_scan_gather_sorted, dim3(nb), dim3(256), 0, s, (const unsigned char*)stage, stride,
+                       total_pts, perm, x, y, z);
 }

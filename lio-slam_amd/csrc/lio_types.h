@@ -65,3 +65,11 @@ struct LioBlockDesc {
     int32_t blk;             // chunk index within the scan
     int32_t n_blk;           // chunks of this scan
 };
+
+// Scan-local tile grid used to re-order a scan at upload (4 m tiles by default).
+struct LioScanTiles {
+    float ox, oy, oz;
+    float inv_tile;
+    int32_t ntx, nty, ntz;
+    int32_t key_offset;      // first tile key of this scan in the batch-wide key space
+};

@@ -74,6 +74,16 @@ struct lio_s2m_handle {
     double* d_partials = nullptr; size_t cap_partials = 0;
     unsigned* d_arrive = nullptr; size_t cap_arrive = 0;
     bool poses_set = false, ran = false;
+    // upload-time tile sort of the scans
+    LioScanTiles* d_tiles = nullptr; size_t cap_tiles = 0;
+    LioBlockDesc* d_prep_blocks = nullptr; size_t cap_prep_blocks = 0;
+    int* d_key_of = nullptr; size_t cap_key_of = 0;
+    int* d_key_count = nullptr; size_t cap_key_count = 0;
+    int* d_key_start = nullptr; size_t cap_key_start = 0;
+    int* d_key_tiles = nullptr; size_t cap_key_tiles = 0;
+    int* d_tmp_idx = nullptr; size_t cap_tmp_idx = 0;
+    int* d_perm = nullptr; size_t cap_perm = 0;
+    bool sorted = false;
 
     // correspondence record (debug / parity)
     unsigned char* d_rec_flag = nullptr; size_t cap_rec_flag = 0;
@@ -123,6 +133,8 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->kernel_variant = 0;
     c->profile = 0;
     c->lookahead = -1;
+    c->use_lds = 1;
+    c->sort_scan = 1;
 }
 
 static void lio_fill_consts(lio_s2m_handle* h)
@@ -179,7 +191,8 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
     void* ptrs[] = { h->d_mx, h->d_my, h->d_mz, h->d_map4, h->d_sorted, h->d_cell_of, h->d_cell_count,
                      h->d_cell_start, h->d_tile_sums, h->d_bbox, h->d_stage, h->d_sx, h->d_sy, h->d_sz,
                      h->d_state, h->d_poses, h->d_blocks, h->d_partials, h->d_arrive, h->d_rec_flag,
-                     h->d_rec_coeff, h->d_rec_nn, h->d_active };
+                     h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
+                     h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) {
         for (int i = 0; i < LIO_MAX_ITERS; ++i) {
@@ -375,12 +388,62 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         HIPCHK(hipMemsetAsync(h->d_rec_coeff, 0, tt * 4 * sizeof(float), h->stream));
         HIPCHK(hipMemsetAsync(h->d_rec_nn, 0xff, tt * 5 * sizeof(int), h->stream));
     }
-    if (total) lio_launch_aos_to_soa(h->d_stage, stride, (int)total, h->d_sx, h->d_sy, h->d_sz, nullptr, h->stream);
     if (!blocks.empty())
         HIPCHK(hipMemcpyAsync(h->d_blocks, blocks.data(), blocks.size() * sizeof(LioBlockDesc),
                               hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state.data(), (size_t)n_scans * sizeof(LioScanState),
                           hipMemcpyHostToDevice, h->stream));
+    std::vector<LioScanTiles> tiles;
+    std::vector<LioBlockDesc> prep;
+    h->sorted = false;
+    if (total && h->cfg.sort_scan) {
+        // scan-local tile grids from the host-side bounding boxes
+        tiles.resize((size_t)n_scans);
+        long long n_keys = 0;
+        for (int s = 0; s < n_scans; ++s) {
+            float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+            const unsigned char* src = (const unsigned char*)scans[s];
+            for (size_t i = 0; i < n_pts[s]; ++i) {
+                const float* p = (const float*)(src + i * stride);
+                for (int a = 0; a < 3; ++a)
+                    if (fabsf(p[a]) <= 3.0e38f) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
+            }
+            for (int a = 0; a < 3; ++a) if (!(mn[a] <= mx[a])) { mn[a] = 0.0f; mx[a] = 0.0f; }
+            float tile = 4.0f;
+            LioScanTiles t;
+            for (;;) {
+                t.inv_tile = 1.0f / tile;
+                const double ex = floor(((double)mx[0] - mn[0]) * t.inv_tile) + 1.0, ey = floor(((double)mx[1] - mn[1]) * t.inv_tile) + 1.0,
+                             ez = floor(((double)mx[2] - mn[2]) * t.inv_tile) + 1.0;
+                if (ex * ey * ez <= 262144.0) { t.ntx = (int)ex; t.nty = (int)ey; t.ntz = (int)ez; break; }
+                tile *= 2.0f;
+            }
+            t.ox = mn[0]; t.oy = mn[1]; t.oz = mn[2];
+            t.key_offset = (int)n_keys;
+            tiles[s] = t;
+            n_keys += (long long)t.ntx * t.nty * t.ntz;
+            const int nb1 = (int)((n_pts[s] + LIO_BLOCK - 1) / LIO_BLOCK);
+            for (int b = 0; b < nb1; ++b) prep.push_back({ s, b * LIO_BLOCK, b, nb1 });
+        }
+        if (n_keys < 0x7fffffffLL - 1024) {
+            HIPCHK(lio_grow(&h->d_tiles, &h->cap_tiles, (size_t)n_scans));
+            HIPCHK(lio_grow(&h->d_prep_blocks, &h->cap_prep_blocks, prep.size()));
+            HIPCHK(lio_grow(&h->d_key_of, &h->cap_key_of, tt));
+            HIPCHK(lio_grow(&h->d_tmp_idx, &h->cap_tmp_idx, tt));
+            HIPCHK(lio_grow(&h->d_perm, &h->cap_perm, tt));
+            HIPCHK(lio_grow(&h->d_key_count, &h->cap_key_count, (size_t)n_keys));
+            HIPCHK(lio_grow(&h->d_key_start, &h->cap_key_start, (size_t)n_keys + 1));
+            HIPCHK(lio_grow(&h->d_key_tiles, &h->cap_key_tiles, (size_t)lio_scan_tiles((int)n_keys) + 1));
+            HIPCHK(hipMemcpyAsync(h->d_tiles, tiles.data(), tiles.size() * sizeof(LioScanTiles), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_prep_blocks, prep.data(), prep.size() * sizeof(LioBlockDesc), hipMemcpyHostToDevice, h->stream));
+            lio_launch_scan_tile_sort(h->d_stage, stride, (int)total, h->d_prep_blocks, (int)prep.size(), h->d_state,
+                                      h->d_tiles, (int)n_keys, h->d_key_of, h->d_key_count, h->d_key_start,
+                                      h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_sx, h->d_sy, h->d_sz, h->stream);
+            h->sorted = true;
+        }
+    }
+    if (total && !h->sorted)
+        lio_launch_aos_to_soa(h->d_stage, stride, (int)total, h->d_sx, h->d_sy, h->d_sz, nullptr, h->stream);
     HIPCHK(hipMemsetAsync(h->d_arrive, 0, (size_t)n_scans * sizeof(unsigned), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));   // `blocks` and the caller's scans are borrowed only for this call
     HIPCHK(hipGetLastError());
@@ -424,6 +487,7 @@ static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_ou
     P.map_xyz4 = h->d_map4;
     P.cell_start = h->d_cell_start;
     P.sx = h->d_sx; P.sy = h->d_sy; P.sz = h->d_sz;
+    P.perm = h->sorted ? h->d_perm : nullptr;
     P.state = h->d_state;
     P.blocks = h->d_blocks;
     P.partials = h->d_partials;
@@ -471,7 +535,7 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
             if (h->h_active[chk] == 0) break;
         }
         if (prof) HIPCHK(hipEventRecord(h->ev_beg[it], h->stream));
-        lio_launch_iterate(P, h->n_blocks, h->ppt, h->stream);
+        lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
         if (prof) HIPCHK(hipEventRecord(h->ev_end[it], h->stream));
         HIPCHK(hipMemcpyAsync(&h->h_active[it], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipEventRecord(h->ev_chk[it], h->stream));
@@ -490,7 +554,7 @@ extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
     LioIterParams P;
     lio_fill_params(h, P, d_sums);
     HIPCHK(hipMemsetAsync(d_sums, 0, (size_t)h->n_scans * LIO_SUMS * sizeof(double), h->stream));
-    lio_launch_iterate(P, h->n_blocks, h->ppt, h->stream);
+    lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
     h->launches_this_run++;
     HIPCHK(hipGetLastError());
     return LIO_OK;

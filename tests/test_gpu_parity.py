@@ -23,6 +23,8 @@ def _run_both(pkg, oracle, scan, map_xyz, pose0, corr_iter=0, **cfg):
     corr = s2m.get_correspondences(0)
     ocfg = oracle.default_config(knn_mode=1, n_threads=8,
                                  **{k: v for k, v in cfg.items() if k in ("jacobian_mode", "force_all_iters", "max_iters")})
+    if "cell_size" in cfg:
+        pass   # grid granularity never changes results (exact search)
     pose_o, res_o, matP_o, corr_o = oracle.scan2map(ocfg, scan, map_xyz, pose0, corr_iter=corr_iter)
     s2m.close()
     return (pose, res, rc, corr), (pose_o, res_o, matP_o, corr_o)
@@ -52,6 +54,19 @@ def test_register_matches_oracle(pkg, oracle, small_case):
         # known answer: the true pose is recovered
         assert np.abs(g[0][3:] - q["pose_true"][3:]).max() < 0.05
         assert np.abs(g[0][:3] - q["pose_true"][:3]).max() < 0.01
+
+
+@pytest.mark.parametrize("variant", [
+    dict(use_lds=0, sort_scan=0), dict(use_lds=1, sort_scan=0), dict(use_lds=0, sort_scan=1),
+    dict(use_lds=1, sort_scan=1, kernel_variant=2), dict(use_lds=1, sort_scan=1, kernel_variant=4),
+    dict(use_lds=0, sort_scan=1, kernel_variant=4), dict(use_lds=1, sort_scan=1, cell_size=2.5),
+])
+def test_kernel_variants_are_equivalent(pkg, oracle, small_case, variant):
+    """LDS-staged vs global candidate scan, sorted vs caller-order scans, points
+    per thread, coarser grid: all exact searches -> identical correspondences."""
+    q = small_case["queries"][2]
+    g, o = _run_both(pkg, oracle, q["scan"], small_case["map"], q["pose_init"], corr_iter=1, **variant)
+    _assert_parity(g, o)
 
 
 def test_later_iteration_association(pkg, oracle, small_case):
