@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--latency", action="store_true", help="also time single-scan registrations")
+    ap.add_argument("--case-cache", default="", help="npz path: load the synthetic case if present, else generate and save")
+    ap.add_argument("--lds", type=int, default=0)
+    ap.add_argument("--sort", type=int, default=1)
+    ap.add_argument("--celldiv", type=int, default=2)
     args = ap.parse_args()
 
     import torch
@@ -118,19 +122,31 @@ def main():
     # ---------------------------------------------------------------- data
     B = args.batch * world
     t0 = time.time()
-    case = synth.make_case(args.sensor, n_keyframes=args.keyframes, seed=synth.BASE_SEED, n_queries=B,
-                           device=f"cuda:{local_rank}",
-                           progress=lambda k, n: log(f"map keyframe {k}/{n}"))
-    map_xyz = case["map"]
-    scans = [q["scan"] for q in case["queries"]]
-    poses0 = np.stack([q["pose_init"] for q in case["queries"]]).astype(np.float32)
-    poses_true = np.stack([q["pose_true"] for q in case["queries"]])
+    if args.case_cache and os.path.exists(args.case_cache):
+        z = np.load(args.case_cache)
+        map_xyz, poses0, poses_true = z["map"], z["poses0"], z["poses_true"]
+        cat, lens = z["scans"], z["lens"]
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        scans = [np.ascontiguousarray(cat[offs[i]:offs[i + 1]]) for i in range(len(lens))]
+        assert len(scans) == B, "case cache was generated for another batch size"
+    else:
+        case = synth.make_case(args.sensor, n_keyframes=args.keyframes, seed=synth.BASE_SEED, n_queries=B,
+                               device=f"cuda:{local_rank}",
+                               progress=lambda k, n: log(f"map keyframe {k}/{n}"))
+        map_xyz = case["map"]
+        scans = [q["scan"] for q in case["queries"]]
+        poses0 = np.stack([q["pose_init"] for q in case["queries"]]).astype(np.float32)
+        poses_true = np.stack([q["pose_true"] for q in case["queries"]])
+        if args.case_cache and rank == 0:
+            np.savez(args.case_cache, map=map_xyz, poses0=poses0, poses_true=poses_true,
+                     scans=np.concatenate(scans), lens=np.array([len(s) for s in scans]))
     n_s = np.array([len(s) for s in scans])
     log(f"data: N_m={len(map_xyz)} N_s mean={n_s.mean():.0f} min={n_s.min()} max={n_s.max()} "
         f"B={B} gen {time.time() - t0:.1f}s")
 
     # -------------------------------------------------------------- engine
-    s2m = pkg.ScanToMap(device_id=local_rank, profile=1, lookahead=0, kernel_variant=args.variant)
+    s2m = pkg.ScanToMap(device_id=local_rank, profile=1, lookahead=0, kernel_variant=args.variant,
+                        use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv)
     if world > 1:
         runner = multi.ShardedRunner(s2m, map_xyz, rank, world, dist, torch)
     else:
@@ -200,6 +216,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "kernel": "k_s2m_iterate", "ms_per_launch": ms_per_launch,
             "launches_per_step": int(live.sum()), "algorithmic_bytes_per_launch": bytes_per_launch,
+            "launch_ms": [round(float(v), 4) for v in lms], "launch_points": [int(v) for v in pts_per_launch],
         },
         "map_build_ms": prof0.map_build_ms, "map_upload_ms": prof0.map_upload_ms,
         "grid_cells": int(prof0.n_cells),

@@ -57,7 +57,8 @@ typedef struct lio_s2m_config {
     int32_t jacobian_mode;   /* 0 = reference (MO:1764 as written), 1 = exact derivative   */
     int32_t force_all_iters; /* 1 = ignore the convergence break MO:1857-1858              */
     int32_t device_id;       /* HIP device ordinal                                         */
-    float   cell_size;       /* hash-grid cell edge in metres; 0 = sqrt(max_sq_dist)*1.001 */
+    float   cell_size;       /* search radius covered by the grid neighbourhood, metres;
+                                0 = sqrt(max_sq_dist)*1.001.  Cell edge = cell_size/cell_div */
     int32_t max_batch;       /* capacity: scans resident per batch (>= 1)                  */
     int32_t max_scan_pts;    /* capacity: points per scan                                  */
     int32_t record_corr_iter;/* iteration whose correspondences are kept for
@@ -66,9 +67,12 @@ typedef struct lio_s2m_config {
     int32_t profile;         /* 1 = bracket every GN-iteration launch with HIP events      */
     int32_t lookahead;       /* GN launches enqueued ahead of the convergence check;
                                 0 = never enqueue an empty launch, -1 = auto               */
-    int32_t use_lds;         /* 1 = stage the workgroup's map region through LDS (default) */
+    int32_t use_lds;         /* 1 = stage the workgroup's map region through LDS;
+                                0 (default) = stream the replicated neighbourhood rows     */
     int32_t sort_scan;       /* 1 = re-order scans by 4 m tiles at upload (default);
                                 results are reported in the caller's order either way      */
+    int32_t cell_div;        /* k: cells per search radius (1..3, default 2); the candidate
+                                scan visits (2k+1)^3 cells, map rows are replicated (2k+1)^2 x */
 } lio_s2m_config;
 
 /* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in
@@ -138,6 +142,9 @@ int  lio_s2m_get_correspondences(lio_s2m_handle *h, int32_t scan, uint8_t *flag,
                                  float *coeff4, int32_t *nn_idx5);
 
 int  lio_s2m_get_profile(lio_s2m_handle *h, lio_s2m_profile *out);
+/* Diagnostic (cfg.profile == 2): per-wave phase clock of the last GN launch,
+ * n_blocks x 4 x 8 cycle counters; returns n_blocks.  Not for production. */
+int  lio_s2m_debug_stamps(lio_s2m_handle *h, long long *out, size_t cap_entries);
 
 /* Multi-GPU hooks (one process per GPU; the caller owns the collective).
  * The map given to set_map is this rank's shard INCLUDING a halo of one cell;

@@ -31,6 +31,7 @@ class S2MConfig(C.Structure):
         ("device_id", C.c_int32), ("cell_size", C.c_float), ("max_batch", C.c_int32),
         ("max_scan_pts", C.c_int32), ("record_corr_iter", C.c_int32), ("kernel_variant", C.c_int32),
         ("profile", C.c_int32), ("lookahead", C.c_int32), ("use_lds", C.c_int32), ("sort_scan", C.c_int32),
+        ("cell_div", C.c_int32),
     ]
 
 
@@ -88,7 +89,7 @@ EXPORTS = [
     "lio_s2m_set_global_grid", "lio_s2m_set_shard", "lio_s2m_batch_begin",
     "lio_s2m_batch_iter_partial", "lio_s2m_batch_iter_apply", "lio_s2m_batch_n_active",
     "lio_transform_update", "lio_deskew_default_config", "lio_imu_deskew_info", "lio_deskew",
-    "lio_curvature",
+    "lio_curvature", "lio_s2m_debug_stamps",
 ]
 
 
@@ -136,6 +137,7 @@ def load_library():
     L.lio_deskew.argtypes = [C.POINTER(DeskewConfig), vp, sz, sz, f64, dp, dp, dp, dp, i32, vp, sz,
                              C.POINTER(sz)]
     L.lio_curvature.argtypes = [i32, vp, sz, vp, vp, vp]
+    L.lio_s2m_debug_stamps.argtypes = [vp, vp, sz]
     _LIB = L
     return L
 
@@ -246,6 +248,13 @@ class ScanToMap:
         p = S2MProfile()
         _check(self.lib.lio_s2m_get_profile(self.h, C.byref(p)), "lio_s2m_get_profile")
         return p
+
+    def debug_stamps(self):
+        nb = self.lib.lio_s2m_debug_stamps(self.h, None, 0)
+        out = np.zeros((max(nb, 0), 4, 8), np.int64)
+        if nb > 0:
+            self.lib.lio_s2m_debug_stamps(self.h, out.ctypes.data, out.size)
+        return out
 
     # multi-GPU hooks
     def set_stream(self, hip_stream):

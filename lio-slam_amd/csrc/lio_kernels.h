@@ -11,6 +11,8 @@ struct LioIterParams {
     const float4* map_sorted;      // cell-sorted (x,y,z,bits(orig index))
     const float4* map_xyz4;        // caller order (x,y,z,0) -- the 5 winners are re-read here
     const int* cell_start;         // n_cells + 1
+    const float4* nbr_pts;         // 9x replicated neighbourhood rows (default candidate scan)
+    const int* nbr_start;          // n_cells + 1 run offsets into nbr_pts
     const float* sx;               // batch scan SoA (all scans concatenated)
     const float* sy;
     const float* sz;
@@ -25,6 +27,7 @@ struct LioIterParams {
     unsigned char* rec_flag;       // optional correspondence record (iteration c.record_iter)
     float* rec_coeff;
     int* rec_nn;
+    long long* stamps;             // diagnostic phase clock: [block][wave][8] cycle counters, or null
 };
 
 void lio_launch_aos_to_soa(const void* src, size_t stride, int n, float* x, float* y, float* z,
@@ -32,7 +35,7 @@ void lio_launch_aos_to_soa(const void* src, size_t stride, int n, float* x, floa
 void lio_launch_map_bbox(const float* x, const float* y, const float* z, int n, unsigned* bbox, hipStream_t s);
 void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, const float* z, int n,
                           int* cell_of, int* cell_count, int* cell_start, int* tile_sums,
-                          float4* sorted, hipStream_t s);
+                          float4* sorted, int* nbr_start, float4* nbr_pts, hipStream_t s);
 int  lio_scan_tiles(int n_cells);
 void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c,
                            int* n_active, hipStream_t s);

@@ -13,13 +13,18 @@
 #include "lio_device_math.h"
 #include "lio_kernels.h"
 
+// Map coordinates beyond this magnitude (or non-finite) are left out of the grid:
+// fp32 spacing there is > 1e7 m, they cannot be a neighbour within 1 m of anything,
+// and keeping them out keeps every squared distance finite.
+#define LIO_MAX_COORD 1.0e15f
+
 // ------------------------------------------------------------------ helpers
 LIO_DEV int lio_cell_coord(float v, float origin, float inv_cell, int n)
 {
-    // monotone in v; clamped to [-2, n+1] so that NaN / far-away queries land
-    // outside every 27-neighbourhood instead of overflowing the int conversion
+    // monotone in v; clamped to [-4, n+3] so that NaN / far-away queries land
+    // outside every neighbourhood instead of overflowing the int conversion
     float c = floorf((v - origin) * inv_cell);
-    c = fminf(fmaxf(c, -2.0f), (float)(n + 1));
+    c = fminf(fmaxf(c, -4.0f), (float)(n + 3));
     return (int)c;
 }
 
@@ -55,7 +60,7 @@ __global__ void k_map_bbox(const float* __restrict__ x, const float* __restrict_
         for (int a = 0; a < 3; ++a) {
             // NaN / inf coordinates are ignored for the box (they can never be a
             // neighbour within 1 m of anything)
-            if (fabsf(v[a]) <= 3.0e38f) { mn[a] = fminf(mn[a], v[a]); mx[a] = fmaxf(mx[a], v[a]); }
+            if (fabsf(v[a]) <= LIO_MAX_COORD) { mn[a] = fminf(mn[a], v[a]); mx[a] = fmaxf(mx[a], v[a]); }
         }
     }
 #pragma unroll
@@ -77,6 +82,7 @@ __global__ void k_map_bbox(const float* __restrict__ x, const float* __restrict_
 
 LIO_DEV int lio_map_cell(const LioGrid& g, float px, float py, float pz)
 {
+    if (!(fabsf(px) <= LIO_MAX_COORD && fabsf(py) <= LIO_MAX_COORD && fabsf(pz) <= LIO_MAX_COORD)) return -1;
     const int cx = lio_cell_coord(px, g.ox, g.inv_cell, g.nx);
     const int cy = lio_cell_coord(py, g.oy, g.inv_cell, g.ny);
     const int cz = lio_cell_coord(pz, g.oz, g.inv_cell, g.nz);
@@ -178,6 +184,52 @@ __global__ void k_map_scatter(const float* __restrict__ x, const float* __restri
     sorted[cell_start[c] + slot] = make_float4(x[i], y[i], z[i], __int_as_float(i));
 }
 
+// ---- 9x replicated neighbourhood rows -------------------------------------
+// For the candidate scan every (y,z) row R of the grid gets its own list: all
+// map points of the (2k+1)x(2k+1) rows around R, bucketed by x cell (k = cells
+// per metre of search radius, LioGrid::k).  The (2k+1)^3-cell neighbourhood of
+// a query in cell (cx,cy,cz) is then ONE contiguous run
+// [nbr_start[R*nx + cx-k], nbr_start[R*nx + cx+k+1]) of 16-byte records -- one
+// range lookup and a unit-stride stream per lane instead of many short,
+// divergent runs.  Costs (2k+1)^2 x 16 B of HBM per map point (k=2: 400 MB per
+// million points; sized for 288 GB).  Finer cells (k=2) cut the searched
+// volume from 27 to 15.6 m^3 around a 1 m gate, i.e. ~1.7x fewer candidates.
+__global__ void k_map_nbr_count(LioGrid g, const int* __restrict__ cell_of, int n, int* __restrict__ nbr_count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell_of[i];
+    if (c < 0) return;
+    const int x = c % g.nx, yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
+    for (int dz = -g.k; dz <= g.k; ++dz)
+        for (int dy = -g.k; dy <= g.k; ++dy) {
+            const int yy = y + dy, zz = z + dz;
+            if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz)
+                atomicAdd(&nbr_count[(zz * g.ny + yy) * g.nx + x], 1);
+        }
+}
+
+__global__ void k_map_nbr_scatter(LioGrid g, const float* __restrict__ x_, const float* __restrict__ y_,
+                                  const float* __restrict__ z_, int n, const int* __restrict__ cell_of,
+                                  const int* __restrict__ nbr_start, int* __restrict__ nbr_fill,
+                                  float4* __restrict__ nbr_pts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell_of[i];
+    if (c < 0) return;
+    const float4 rec = make_float4(x_[i], y_[i], z_[i], __int_as_float(i));
+    const int x = c % g.nx, yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
+    for (int dz = -g.k; dz <= g.k; ++dz)
+        for (int dy = -g.k; dy <= g.k; ++dy) {
+            const int yy = y + dy, zz = z + dz;
+            if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+                const int key = (zz * g.ny + yy) * g.nx + x;
+                nbr_pts[nbr_start[key] + atomicAdd(&nbr_fill[key], 1)] = rec;
+            }
+        }
+}
+
 // ------------------------------------------------- scan tile sort (upload)
 // The scan (laserCloudSurfLastDS, MO:138) is re-ordered once per upload so that
 // the 256*PPT consecutive points of an association workgroup lie in a compact
@@ -256,28 +308,39 @@ __global__ void k_scan_gather_sorted(const unsigned char* __restrict__ stage, si
 }
 
 // -------------------------------------------------------------- GN iterate
-// top-5 keys: (bits(d2) << 32) | original index -- d2 >= 0, so the unsigned
-// 64-bit order is the lexicographic (d2, index) order of the exact k-NN
-// (pcl::KdTreeFLANN::nearestKSearch MO:1631: ascending squared distance; ties
-// by the smaller map index).
-LIO_DEV void lio_cswap(unsigned long long& a, unsigned long long& b)
+// top-5 keys.  A key is the fp64 value of the fp32 squared distance with the
+// map index OR-ed into the 29 low mantissa bits that the fp32->fp64 conversion
+// leaves zero: for non-negative doubles the numeric order is the lexicographic
+// (d2, index) order of the exact k-NN (pcl::KdTreeFLANN::nearestKSearch
+// MO:1631: ascending squared distance; ties by the smaller map index).  The
+// sorted insertion is then a branch-free chain of 9 v_min_f64 / v_max_f64.
+#define LIO_IDX_BITS 29
+#define LIO_IDX_MASK 0x1fffffff
+
+LIO_DEV double lio_dmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+LIO_DEV double lio_dmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+LIO_DEV double lio_make_key(float d2, int idx)
 {
-    const unsigned long long lo = a < b ? a : b;
-    const unsigned long long hi = a < b ? b : a;
-    a = lo; b = hi;
+    const double d = (double)d2;                    // exact; low 29 mantissa bits are zero
+    return __hiloint2double(__double2hiint(d), __double2loint(d) | idx);
 }
-
-struct LioTop5 { unsigned long long k0, k1, k2, k3, k4; };
-
-LIO_DEV void lio_top5_insert(LioTop5& t, unsigned long long key)
+LIO_DEV double lio_key_d2(double key)               // the squared distance, exactly
 {
-    if (key < t.k4) {
-        t.k4 = key;
-        lio_cswap(t.k3, t.k4);
-        lio_cswap(t.k2, t.k3);
-        lio_cswap(t.k1, t.k2);
-        lio_cswap(t.k0, t.k1);
-    }
+    return __hiloint2double(__double2hiint(key), __double2loint(key) & ~LIO_IDX_MASK);
+}
+LIO_DEV int lio_key_idx(double key) { return __double2loint(key) & LIO_IDX_MASK; }
+
+struct LioTop5 { double k0, k1, k2, k3, k4; };
+
+LIO_DEV void lio_top5_insert(LioTop5& t, double x)
+{
+    double c;
+    c = lio_dmax(t.k0, x); t.k0 = lio_dmin(t.k0, x); x = c;
+    c = lio_dmax(t.k1, x); t.k1 = lio_dmin(t.k1, x); x = c;
+    c = lio_dmax(t.k2, x); t.k2 = lio_dmin(t.k2, x); x = c;
+    c = lio_dmax(t.k3, x); t.k3 = lio_dmin(t.k3, x); x = c;
+    t.k4 = lio_dmin(t.k4, x);
 }
 
 // FLANN L2_Simple: ((dx*dx) + dy*dy) + dz*dz, accumulated from 0
@@ -407,41 +470,54 @@ __global__ void k_s2m_init_state(LioScanState* __restrict__ st, int n_scans,
 }
 
 // ---- candidate scan, global-memory form -----------------------------------
-// 27-cell neighbourhood = 9 (y,z) rows of three x-adjacent cells = 9 contiguous
-// runs of the cell-sorted map.  The 18 run bounds are fetched first (one memory
-// latency), then the runs are walked four candidates at a time so that four
-// 16-byte loads are in flight per lane.
+// One contiguous run of the replicated neighbourhood row (see k_map_nbr_*),
+// walked four 16-byte records per step with the next four already in flight;
+// full groups run unpredicated, the last partial group is masked.  Clamping
+// cy/cz into the grid selects a superset of the neighbourhood, which keeps the
+// search exact.
+LIO_DEV void lio_knn_group(const float4 (&m)[4], float qx, float qy, float qz, LioTop5& top)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float d2 = lio_sqdist(m[u].x, m[u].y, m[u].z, qx, qy, qz);
+        lio_top5_insert(top, lio_make_key(d2, __float_as_int(m[u].w)));
+    }
+}
+
 LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
                             int cx, int cy, int cz, LioTop5& top)
 {
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+    const int x0 = max(cx - g.k, 0), x1 = min(cx + g.k, g.nx - 1);
     if (x0 > x1) return;
-    int beg[9], end[9];
+    const int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nx;
+    const unsigned beg = (unsigned)P.nbr_start[row + x0];
+    const unsigned end = (unsigned)P.nbr_start[row + x1 + 1];
+    if (beg >= end) return;
+    const unsigned full = beg + ((end - beg) & ~3u);       // end of the last full group
+    const float4* p = P.nbr_pts + beg;
+    const float4* const pl = P.nbr_pts + (end - 1);        // clamp target for run-ahead loads
+    float4 cur[4], nxt[4];
+    if (beg < full) {
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
-        const bool in = (z >= 0) && (z < g.nz) && (y >= 0) && (y < g.ny);
-        const int row = in ? (z * g.ny + y) * g.nx : 0;
-        const int b = P.cell_start[row + x0];
-        const int e = P.cell_start[row + x1 + 1];
-        beg[r] = b;
-        end[r] = in ? e : b;
+        for (int u = 0; u < 4; ++u) cur[u] = p[u];
+        for (unsigned j = beg + 4; j < full; j += 4) {
+            p += 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) nxt[u] = p[u];
+            lio_knn_group(cur, qx, qy, qz, top);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+        }
+        lio_knn_group(cur, qx, qy, qz, top);
     }
+    if (full < end) {                                      // 1..3 leftover records
+        const float4* t = P.nbr_pts + full;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        for (int j = beg[r]; j < end[r]; j += 4) {
-            float4 m[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) m[u] = P.map_sorted[min(j + u, end[r] - 1)];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (j + u < end[r]) {
-                    const float d2 = lio_sqdist(m[u].x, m[u].y, m[u].z, qx, qy, qz);
-                    const unsigned long long key =
-                        ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(m[u].w);
-                    lio_top5_insert(top, key);
-                }
-            }
+        for (int u = 0; u < 3; ++u) {
+            const float4 m = *((t + u < pl) ? t + u : pl);
+            const float d2 = lio_sqdist(m.x, m.y, m.z, qx, qy, qz);
+            const double key = lio_make_key(d2, __float_as_int(m.w));
+            lio_top5_insert(top, (full + u < end) ? key : (double)INFINITY);
         }
     }
 }
@@ -470,13 +546,15 @@ LIO_DEV void lio_knn_lds(const float4* s_pts, const int* s_cell, int rx1, int ry
             for (int j = b; j < e; ++j) {
                 const float4 m = s_pts[j];
                 const float d2 = lio_sqdist(m.x, m.y, m.z, qx, qy, qz);
-                const unsigned long long key =
-                    ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(m.w);
-                lio_top5_insert(top, key);
+                lio_top5_insert(top, lio_make_key(d2, __float_as_int(m.w)));
             }
         }
     }
 }
+
+// (a, b) column pair of each of the 28 sums: 21 upper-triangle JtJ, 6 Jtr, N_c
+__constant__ int c_pair_a[32] = { 0,0,0,0,0,0, 1,1,1,1,1, 2,2,2,2, 3,3,3, 4,4, 5,  0,1,2,3,4,5, 7, 0,0,0,0 };
+__constant__ int c_pair_b[32] = { 0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5, 4,5, 5,  6,6,6,6,6,6, 7, 0,0,0,0 };
 
 #define LIO_LDS_PTS   2048     // staged map points per workgroup (32 KiB)
 #define LIO_LDS_CELLS 1536     // staged run offsets (6 KiB)
@@ -491,7 +569,8 @@ LIO_DEV void lio_knn_lds(const float4* s_pts, const int* s_cell, int rx1, int ry
 template <int PPT, bool STAGE>
 __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
 {
-    __shared__ double s_part[LIO_BLOCK / 64][28];
+    __shared__ __attribute__((aligned(16))) float s_rows[LIO_BLOCK][8];   // [arz ary arx cx cy cz | -cw | accepted]
+    __shared__ double s_part[8][28];
     __shared__ double s_sum[28];
     __shared__ LioSolveWs s_ws;
     __shared__ __attribute__((aligned(16))) float4 s_pts[STAGE ? LIO_LDS_PTS : 1];
@@ -504,6 +583,10 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
     const LioBlockDesc bd = P.blocks[blockIdx.x];
     LioScanState* st = &P.state[bd.scan];
     if (st->done) return;                                  // workgroup-uniform
+    // diagnostic phase clock (P.stamps is null outside profiling experiments)
+    long long* stamp = P.stamps ? P.stamps + ((size_t)blockIdx.x * (LIO_BLOCK / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
+#define LIO_STAMP(k) do { if (stamp && (threadIdx.x & 63) == 0) stamp[k] = (long long)__builtin_readcyclecounter(); } while (0)
+    LIO_STAMP(0);
 
     // wave-uniform per-scan values
     float T[12], tr[6];
@@ -542,7 +625,8 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
         cy[pp] = lio_cell_coord(qy[pp], g.oy, g.inv_cell, g.ny);
         cz[pp] = lio_cell_coord(qz[pp], g.oz, g.inv_cell, g.nz);
         // a point whose 27 cells all lie outside the grid has no candidates at all
-        a = a && cx[pp] >= -1 && cx[pp] <= g.nx && cy[pp] >= -1 && cy[pp] <= g.ny && cz[pp] >= -1 && cz[pp] <= g.nz;
+        a = a && cx[pp] >= -g.k && cx[pp] < g.nx + g.k && cy[pp] >= -g.k && cy[pp] < g.ny + g.k &&
+            cz[pp] >= -g.k && cz[pp] < g.nz + g.k;
         act[pp] = a;
         if (STAGE && a) {
             bmn[0] = min(bmn[0], cx[pp]); bmx[0] = max(bmx[0], cx[pp]);
@@ -617,15 +701,20 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
         }
     }
 
-    double acc[28];
-#pragma unroll
-    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+    // Normal equations (matAtA = matAt*matA, matAtB = matAt*matB, MO:1781-1783) as
+    // a transposed reduction: every lane parks its Jacobian row in LDS, then lane
+    // (g, s) = (tid / 32, tid % 32) accumulates sum s over the points p = g (mod 8)
+    // in fp64.  One accumulator per lane instead of 28, no cross-lane shuffles,
+    // fixed summation order.
+    const int red_g = threadIdx.x >> 5, red_s = threadIdx.x & 31;
+    const int red_a = c_pair_a[red_s], red_b = c_pair_b[red_s];
+    double red_acc = 0.0;
+    LIO_STAMP(1);
 
 #pragma unroll 1
     for (int pp = 0; pp < PPT; ++pp) {
         // ---- exact 5-NN over the 27-cell neighbourhood (MO:1631) ----
-        const unsigned long long sentinel =
-            ((unsigned long long)__float_as_uint(P.c.max_sq_dist) << 32) | 0x7fffffffull;
+        const double sentinel = lio_make_key(P.c.max_sq_dist, LIO_IDX_MASK);
         LioTop5 top = { sentinel, sentinel, sentinel, sentinel, sentinel };
         if (act[pp]) {
             if (STAGE && staged)
@@ -635,11 +724,11 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
                 lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], top);
         }
         // gate MO:1641: pointSearchSqDis[4] < 1.0
-        const float d4 = __uint_as_float((unsigned)(top.k4 >> 32));
-        const bool ok = act[pp] && (d4 < P.c.max_sq_dist);
+        const bool ok = act[pp] && (lio_key_d2(top.k4) < (double)P.c.max_sq_dist);
+        if (pp == 0) LIO_STAMP(2);
 
-        int nn[5] = { (int)(unsigned)top.k0, (int)(unsigned)top.k1, (int)(unsigned)top.k2,
-                      (int)(unsigned)top.k3, (int)(unsigned)top.k4 };
+        int nn[5] = { lio_key_idx(top.k0), lio_key_idx(top.k1), lio_key_idx(top.k2),
+                      lio_key_idx(top.k3), lio_key_idx(top.k4) };
         float cxx = 0.0f, cyy = 0.0f, czz = 0.0f, cww = 0.0f;
         bool accept = false;
         if (ok) {
@@ -681,35 +770,31 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
 #pragma unroll
             for (int j = 0; j < 5; ++j) P.rec_nn[(size_t)oi * 5 + j] = ok ? nn[j] : -1;
         }
-        if (accept) {
-            // MO:1735-1783: row of matA/matB, outer products accumulated in double
-            float row[6], rhs;
-            lio_jacobian_row(tr, px[pp], py[pp], pz[pp], cxx, cyy, czz, cww, P.c.jac_exact, row, rhs);
-            int p = 0;
-#pragma unroll
-            for (int a2 = 0; a2 < 6; ++a2)
-#pragma unroll
-                for (int b2 = a2; b2 < 6; ++b2) acc[p++] += (double)row[a2] * (double)row[b2];
-#pragma unroll
-            for (int a2 = 0; a2 < 6; ++a2) acc[21 + a2] += (double)row[a2] * (double)rhs;
-            acc[27] += 1.0;
+        // MO:1735-1778: row of matA / matB (zero row when the point is rejected)
+        float row[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, rhs = 0.0f;
+        if (accept) lio_jacobian_row(tr, px[pp], py[pp], pz[pp], cxx, cyy, czz, cww, P.c.jac_exact, row, rhs);
+        if (PPT > 1) __syncthreads();                                  // previous pass finished reading
+        reinterpret_cast<float4*>(s_rows[threadIdx.x])[0] = make_float4(row[0], row[1], row[2], row[3]);
+        reinterpret_cast<float4*>(s_rows[threadIdx.x])[1] = make_float4(row[4], row[5], rhs, accept ? 1.0f : 0.0f);
+        if (pp == 0) LIO_STAMP(3);
+        __syncthreads();
+        if (red_s < 28) {
+#pragma unroll 8
+            for (int p = red_g; p < LIO_BLOCK; p += 8)
+                red_acc += (double)s_rows[p][red_a] * (double)s_rows[p][red_b];
         }
     }
-
-    // ---- workgroup reduction: wave butterfly -> LDS -> fixed-order sum ----
-#pragma unroll
-    for (int k = 0; k < 28; ++k) {
-        const double v = lio_wave_sum(acc[k]);
-        if (lane == 0) s_part[wave][k] = v;
-    }
+    LIO_STAMP(4);
+    if (red_s < 28) s_part[red_g][red_s] = red_acc;
     __syncthreads();
+    LIO_STAMP(5);
     if (wave != 0) return;
 
     double* part = P.partials + ((size_t)bd.scan * P.max_blk + bd.blk) * LIO_SUMS;
     if (lane < 28) {
         double v = s_part[0][lane];
 #pragma unroll
-        for (int w = 1; w < LIO_BLOCK / 64; ++w) v += s_part[w][lane];
+        for (int w = 1; w < 8; ++w) v += s_part[w][lane];
         // write-through (sc1) store: visible to the other XCDs without a release fence
         __hip_atomic_store(part + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -720,14 +805,22 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
         last = (old == (unsigned)bd.n_blk - 1u);
     }
     last = __shfl(last, 0);
+    LIO_STAMP(6);
     if (!last) return;
 
     // last workgroup of this scan: fixed-order sum over the scan's chunks
     if (lane < 28) {
         const double* base_p = P.partials + (size_t)bd.scan * P.max_blk * LIO_SUMS + lane;
         double v = 0.0;
-        for (int b = 0; b < bd.n_blk; ++b)
-            v += __hip_atomic_load(base_p + (size_t)b * LIO_SUMS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int b = 0; b < bd.n_blk; b += 8) {          // 8 write-through loads in flight, summed in chunk order
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                t[u] = __hip_atomic_load(base_p + (size_t)min(b + u, bd.n_blk - 1) * LIO_SUMS,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += (b + u < bd.n_blk) ? t[u] : 0.0;
+        }
         s_sum[lane] = v;
         if (P.sums_out) P.sums_out[(size_t)bd.scan * LIO_SUMS + lane] = v;
     }
@@ -736,6 +829,8 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
         P.arrive[bd.scan] = 0;            // re-arm for the next launch
         if (!P.sums_out) lio_gn_step(st, s_sum, P.c, &s_ws, P.n_active);
     }
+    LIO_STAMP(7);
+#undef LIO_STAMP
 }
 
 // Sharded mode: solve every scan from all-reduced sums (one lane per scan).
@@ -765,19 +860,31 @@ void lio_launch_map_bbox(const float* x, const float* y, const float* z, int n, 
     hipLaunchKernelGGL(k_map_bbox, dim3(blocks), dim3(256), 0, s, x, y, z, n, bbox);
 }
 
+static void lio_exclusive_scan(const int* in, int n, int* tile_sums, int* out, hipStream_t s)
+{
+    const int n_tiles = (n + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, s, in, n, tile_sums);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(256), 0, s, tile_sums, n_tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_tiles), dim3(256), 0, s, in, n, tile_sums, out);
+}
+
 void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, const float* z, int n,
                           int* cell_of, int* cell_count, int* cell_start, int* tile_sums,
-                          float4* sorted, hipStream_t s)
+                          float4* sorted, int* nbr_start, float4* nbr_pts, hipStream_t s)
 {
     const int nb = (n + 255) / 256;
+    // cell-sorted copy (1x): used by the LDS-staged variant
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
     hipLaunchKernelGGL(k_map_cell_count, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, cell_count);
-    const int n_tiles = (g.n_cells + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, s, cell_count, g.n_cells, tile_sums);
-    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(256), 0, s, tile_sums, n_tiles);
-    hipLaunchKernelGGL(k_scan_apply, dim3(n_tiles), dim3(256), 0, s, cell_count, g.n_cells, tile_sums, cell_start);
+    lio_exclusive_scan(cell_count, g.n_cells, tile_sums, cell_start, s);
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);   // reused as the fill cursor
     hipLaunchKernelGGL(k_map_scatter, dim3(nb), dim3(256), 0, s, x, y, z, n, cell_of, cell_start, cell_count, sorted);
+    // replicated neighbourhood rows (9x): used by the default candidate scan
+    (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
+    hipLaunchKernelGGL(k_map_nbr_count, dim3(nb), dim3(256), 0, s, g, cell_of, n, cell_count);
+    lio_exclusive_scan(cell_count, g.n_cells, tile_sums, nbr_start, s);
+    (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
+    hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, nbr_start, cell_count, nbr_pts);
 }
 
 int lio_scan_tiles(int n_cells) { return (n_cells + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE; }

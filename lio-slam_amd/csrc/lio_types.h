@@ -16,6 +16,7 @@ struct LioGrid {
     float inv_cell;
     int32_t nx, ny, nz;
     int32_t n_cells;
+    int32_t k;          // neighbourhood radius in cells (cell edge = search radius / k)
 };
 
 // Owner-computes predicate for a map sharded across GPUs: a scan

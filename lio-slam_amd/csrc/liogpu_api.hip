@@ -58,6 +58,8 @@ struct lio_s2m_handle {
     int* d_cell_count = nullptr; size_t cap_cell_count = 0;
     int* d_cell_start = nullptr; size_t cap_cell_start = 0;
     int* d_tile_sums = nullptr;  size_t cap_tile_sums = 0;
+    int* d_nbr_start = nullptr;  size_t cap_nbr_start = 0;
+    float4* d_nbr_pts = nullptr; size_t cap_nbr_pts = 0;
     unsigned* d_bbox = nullptr;
     unsigned char* d_stage = nullptr; size_t cap_stage = 0;
     LioGrid grid{};
@@ -84,6 +86,7 @@ struct lio_s2m_handle {
     int* d_tmp_idx = nullptr; size_t cap_tmp_idx = 0;
     int* d_perm = nullptr; size_t cap_perm = 0;
     bool sorted = false;
+    long long* d_stamps = nullptr; size_t cap_stamps = 0;
 
     // correspondence record (debug / parity)
     unsigned char* d_rec_flag = nullptr; size_t cap_rec_flag = 0;
@@ -133,7 +136,8 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->kernel_variant = 0;
     c->profile = 0;
     c->lookahead = -1;
-    c->use_lds = 1;
+    c->use_lds = 0;
+    c->cell_div = 2;
     c->sort_scan = 1;
 }
 
@@ -161,7 +165,7 @@ extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
     HIPCHK(hipSetDevice(cfg->device_id));
     lio_s2m_handle* h = new lio_s2m_handle();
     h->cfg = *cfg;
-    if (h->cfg.cell_size > 0.0f && h->cfg.cell_size < sqrtf(h->cfg.max_sq_dist) * 1.001f) {
+    if (h->cfg.cell_size > 0.0f && h->cfg.cell_size < sqrtf(h->cfg.max_sq_dist) * 1.001f) {   // (before division by cell_div)
         delete h;
         return lio_fail(LIO_ERR_ARG, "cell_size must be >= sqrt(max_sq_dist)*1.001 for an exact 27-cell search");
     }
@@ -192,7 +196,7 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_cell_start, h->d_tile_sums, h->d_bbox, h->d_stage, h->d_sx, h->d_sy, h->d_sz,
                      h->d_state, h->d_poses, h->d_blocks, h->d_partials, h->d_arrive, h->d_rec_flag,
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
-                     h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm };
+                     h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) {
         for (int i = 0; i < LIO_MAX_ITERS; ++i) {
@@ -230,7 +234,7 @@ extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, siz
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     if (n > 0 && !pts) return lio_fail(LIO_ERR_ARG, "null map pointer");
     if (stride < 12 || (stride & 3)) return lio_fail(LIO_ERR_ARG, "stride_bytes must be >= 12 and a multiple of 4");
-    if (n > 0x7fffffffull - 1024) return lio_fail(LIO_ERR_CAPACITY, "map too large");
+    if (n >= (1ull << 25)) return lio_fail(LIO_ERR_CAPACITY, "map too large ((2k+1)^2 x n records must fit a 31-bit offset)");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     auto t0 = std::chrono::steady_clock::now();
     h->has_map = false;
@@ -260,9 +264,14 @@ extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, siz
     bool empty = (n == 0) || hb[0] == 0xffffffffu;
     for (int a = 0; a < 3; ++a) { mn[a] = empty ? 0.0f : lio_ord2f(hb[a]); mx[a] = empty ? 0.0f : lio_ord2f(hb[3 + a]); }
 
-    float cell = h->cfg.cell_size > 0.0f ? h->cfg.cell_size : sqrtf(h->cfg.max_sq_dist) * 1.001f;
+    // cell edge = gate radius (+0.1 %) / k; the candidate scan visits (2k+1)^3 cells
+    int kdiv = h->cfg.cell_div;
+    if (kdiv != 1 && kdiv != 2 && kdiv != 3) kdiv = 2;
+    if (h->cfg.use_lds) kdiv = 1;                      // the LDS-staged variant assumes a one-cell halo
+    float cell = (h->cfg.cell_size > 0.0f ? h->cfg.cell_size : sqrtf(h->cfg.max_sq_dist) * 1.001f) / (float)kdiv;
     LioGrid g;
     for (;;) {
+        g.k = kdiv;
         g.inv_cell = 1.0f / cell;
         g.ox = mn[0] - 0.5f * cell; g.oy = mn[1] - 0.5f * cell; g.oz = mn[2] - 0.5f * cell;
         const double ex = ((double)mx[0] - g.ox) * g.inv_cell, ey = ((double)mx[1] - g.oy) * g.inv_cell,
@@ -273,19 +282,22 @@ extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, siz
             g.n_cells = g.nx * g.ny * g.nz;
             break;
         }
-        cell *= 1.5f;   // larger cells keep the 27-cell search exact, only less selective
+        cell *= 1.5f;   // larger cells keep the search exact, only less selective
     }
     h->grid = g;
     HIPCHK(lio_grow(&h->d_cell_count, &h->cap_cell_count, (size_t)g.n_cells));
     HIPCHK(lio_grow(&h->d_cell_start, &h->cap_cell_start, (size_t)g.n_cells + 1));
+    HIPCHK(lio_grow(&h->d_nbr_start, &h->cap_nbr_start, (size_t)g.n_cells + 1));
+    HIPCHK(lio_grow(&h->d_nbr_pts, &h->cap_nbr_pts, nn * (size_t)((2 * g.k + 1) * (2 * g.k + 1)), 1.05));
     HIPCHK(lio_grow(&h->d_tile_sums, &h->cap_tile_sums, (size_t)lio_scan_tiles(g.n_cells) + 1));
 
     HIPCHK(hipEventRecord(h->ev_map[0], h->stream));
     if (n) {
         lio_launch_map_build(g, h->d_mx, h->d_my, h->d_mz, (int)n, h->d_cell_of, h->d_cell_count,
-                             h->d_cell_start, h->d_tile_sums, h->d_sorted, h->stream);
+                             h->d_cell_start, h->d_tile_sums, h->d_sorted, h->d_nbr_start, h->d_nbr_pts, h->stream);
     } else {
         HIPCHK(hipMemsetAsync(h->d_cell_start, 0, sizeof(int) * ((size_t)g.n_cells + 1), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_nbr_start, 0, sizeof(int) * ((size_t)g.n_cells + 1), h->stream));
     }
     HIPCHK(hipEventRecord(h->ev_map[1], h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -380,6 +392,10 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     h->max_blk = max_blk;
     HIPCHK(lio_grow(&h->d_blocks, &h->cap_blocks, blocks.size() ? blocks.size() : 1));
     HIPCHK(lio_grow(&h->d_partials, &h->cap_partials, (size_t)n_scans * max_blk * LIO_SUMS));
+    if (h->cfg.profile == 2) {
+        HIPCHK(lio_grow(&h->d_stamps, &h->cap_stamps, blocks.size() * (LIO_BLOCK / 64) * 8 + 8));
+        HIPCHK(hipMemsetAsync(h->d_stamps, 0, (blocks.size() * (LIO_BLOCK / 64) * 8 + 8) * sizeof(long long), h->stream));
+    }
     if (h->cfg.record_corr_iter >= 0) {
         HIPCHK(lio_grow(&h->d_rec_flag, &h->cap_rec_flag, tt));
         HIPCHK(lio_grow(&h->d_rec_coeff, &h->cap_rec_coeff, tt * 4));
@@ -486,6 +502,8 @@ static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_ou
     P.map_sorted = h->d_sorted;
     P.map_xyz4 = h->d_map4;
     P.cell_start = h->d_cell_start;
+    P.nbr_pts = h->d_nbr_pts;
+    P.nbr_start = h->d_nbr_start;
     P.sx = h->d_sx; P.sy = h->d_sy; P.sz = h->d_sz;
     P.perm = h->sorted ? h->d_perm : nullptr;
     P.state = h->d_state;
@@ -499,6 +517,7 @@ static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_ou
     P.rec_flag = rec ? h->d_rec_flag : nullptr;
     P.rec_coeff = rec ? h->d_rec_coeff : nullptr;
     P.rec_nn = rec ? h->d_rec_nn : nullptr;
+    P.stamps = (h->cfg.profile == 2) ? h->d_stamps : nullptr;
 }
 
 extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
@@ -791,4 +810,16 @@ extern "C" int lio_imu_deskew_info(const double* stamp, const double* gx, const 
         ++cur;
     }
     return cur - 1;                                      // IP:412
+}
+
+// Diagnostic: phase clock of the LAST iterate launch (cfg.profile == 2):
+// n_blocks x 4 waves x 8 cycle counters.  Returns the number of blocks.
+extern "C" int lio_s2m_debug_stamps(lio_s2m_handle* h, long long* out, size_t cap_entries)
+{
+    if (!h || !h->d_stamps) return 0;
+    const size_t n = (size_t)h->n_blocks * (LIO_BLOCK / 64) * 8;
+    if (out && cap_entries >= n) {
+        if (hipMemcpy(out, h->d_stamps, n * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    return h->n_blocks;
 }

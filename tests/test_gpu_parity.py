@@ -60,6 +60,7 @@ def test_register_matches_oracle(pkg, oracle, small_case):
     dict(use_lds=0, sort_scan=0), dict(use_lds=1, sort_scan=0), dict(use_lds=0, sort_scan=1),
     dict(use_lds=1, sort_scan=1, kernel_variant=2), dict(use_lds=1, sort_scan=1, kernel_variant=4),
     dict(use_lds=0, sort_scan=1, kernel_variant=4), dict(use_lds=1, sort_scan=1, cell_size=2.5),
+    dict(cell_div=1), dict(cell_div=2, cell_size=1.7), dict(cell_div=3, sort_scan=0),
 ])
 def test_kernel_variants_are_equivalent(pkg, oracle, small_case, variant):
     """LDS-staged vs global candidate scan, sorted vs caller-order scans, points
@@ -165,3 +166,22 @@ def test_pcl_stride_input(pkg, small_case):
     p2, r2, _ = s2m.scan2MapOptimization(pcl(q["scan"]), q["pose_init"])
     assert np.array_equal(p1, p2) and r1.iters == r2.iters
     s2m.close()
+
+
+def test_exact_ties_and_coincident_points(pkg, oracle):
+    """Lattice map (many exactly equal distances) + scan points ON map points
+    (d2 == 0 -> denormal fp64 keys): the (d2, index) tie-break must match."""
+    g = np.arange(0, 6, 0.5, dtype=np.float32)
+    lattice = np.stack(np.meshgrid(g, g, np.array([0.0, 0.5], np.float32), indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(0)
+    map_xyz = np.concatenate([lattice, lattice[::5]]).astype(np.float32)     # duplicates: ties at d2 == 0 too
+    scan = np.concatenate([lattice[::3] + np.float32(0.25), lattice[1::7],
+                           rng.uniform(0.5, 5.5, (200, 3)).astype(np.float32) * np.array([1, 1, 0.1], np.float32)])
+    pose0 = np.zeros(6, np.float32)
+    for variant in (dict(use_lds=0), dict(use_lds=1)):
+        g_, o_ = _run_both(pkg, oracle, scan, map_xyz, pose0, corr_iter=0, max_iters=1, **variant)
+        flag, coeff, nn = g_[3]
+        flag_o, coeff_o, nn_o = o_[3]
+        assert np.array_equal(nn, nn_o)
+        assert np.array_equal(flag, flag_o)
+        assert (nn_o[:, 4] >= 0).sum() > 100
