@@ -47,12 +47,25 @@ def rmse_pair(poses_a, poses_b, synth):
     return float(np.sqrt((dt ** 2).mean())), float(np.sqrt((dr ** 2).mean()))
 
 
+def host_cores():
+    """CPU threads this process may really use: the cgroup quota when there is one
+    (a 1-GPU box gets a 16-core share of a 256-thread host), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(scans, map_xyz, poses0, budget_s, log):
     """CPU restatement of the reference loop (oracle, own kd-tree incl. the per-scan
     tree build MO:1846, OpenMP over scan points MO:1622) on a bounded sample."""
     from oracle.oracle import Oracle, build
     import tempfile
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     try:
         so = build(fast=True, out_dir=tempfile.mkdtemp(prefix="lio_oracle_"))
         kind_flags = "-O3 -march=native"
@@ -83,12 +96,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="scans per GPU per step")
+    ap.add_argument("--batch", type=int, default=512, help="scans per GPU per step")
     ap.add_argument("--sensor", default="hdl64")
     ap.add_argument("--keyframes", type=int, default=200)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=2, help="scan points per thread (1, 2, 4)")
     ap.add_argument("--latency", action="store_true", help="also time single-scan registrations")
     ap.add_argument("--case-cache", default="", help="npz path: load the synthetic case if present, else generate and save")
     ap.add_argument("--lds", type=int, default=0)
@@ -197,6 +210,13 @@ def main():
     ms_per_launch = float(lms[live].mean()) if live.any() else float("nan")
     achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if live.any() else 0.0
 
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath) and world == 1:
+        tj = json.load(open(tpath))
+        if (tj.get("scans_per_step"), tj.get("N_m")) == (B, int(len(map_xyz))):
+            traffic = tj["hbm_bytes_per_launch"]      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see DESIGN.md
+
     value = B * args.steps / elapsed
     out = {
         "metric": "scan-to-map registrations/sec, 64x1800 scan vs 200-keyframe map; pose RMSE",
@@ -209,11 +229,12 @@ def main():
             "scans_per_step": B, "N_s_mean": float(n_s.mean()), "N_m": int(len(map_xyz)),
             "gn_iters_mean": float(iters.mean()), "gn_iters_max": int(iters.max()),
             "parallelism": "single GPU" if world == 1 else f"map sharded x{world} + RCCL all-reduce of JtJ/Jtr per GN iteration",
-            "kernel_ppt": int(args.variant),
+            "kernel": {"points_per_thread": int(args.variant), "lds_staging": int(args.lds),
+                       "tile_sorted_scans": int(args.sort), "cell_div": int(args.celldiv)},
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": "k_s2m_iterate", "ms_per_launch": ms_per_launch,
             "launches_per_step": int(live.sum()), "algorithmic_bytes_per_launch": bytes_per_launch,
             "launch_ms": [round(float(v), 4) for v in lms], "launch_points": [int(v) for v in pts_per_launch],

@@ -26,7 +26,7 @@ def default_cell(max_sq_dist=1.0):
 def cell_coord(v, origin, inv_cell, n):
     """fp32 cell index exactly as lio_cell_coord() in csrc/lio_kernels.hip."""
     c = np.floor((np.asarray(v, np.float32) - np.float32(origin)) * np.float32(inv_cell))
-    c = np.minimum(np.maximum(c, np.float32(-2.0)), np.float32(n + 1))
+    c = np.minimum(np.maximum(c, np.float32(-4.0)), np.float32(n + 3))
     return c.astype(np.int64)
 
 
@@ -113,7 +113,7 @@ class ShardedRunner:
         n = s2m._n_scans
         if self.sums is None or self.sums.shape[0] != n:
             self.sums = torch.zeros((n, SUMS), dtype=torch.float64, device="cuda")
-            self.gathered = torch.zeros((self.world, n, SUMS), dtype=torch.float64, device="cuda")
+            self.gathered = torch.zeros((self.world * n, SUMS), dtype=torch.float64, device="cuda")
         s2m.batch_begin()
         iters = 0
         for it in range(s2m.cfg.max_iters):                      # MO:1848
@@ -121,9 +121,10 @@ class ShardedRunner:
             if self.deterministic:
                 # bitwise reproducible across runs: gather, then sum in rank order
                 dist.all_gather_into_tensor(self.gathered, self.sums)
-                self.sums.copy_(self.gathered[0])
+                g = self.gathered.view(self.world, n, SUMS)
+                self.sums.copy_(g[0])
                 for r in range(1, self.world):
-                    self.sums.add_(self.gathered[r])
+                    self.sums.add_(g[r])
             else:
                 dist.all_reduce(self.sums, op=dist.ReduceOp.SUM)
             s2m.batch_iter_apply(self.sums.data_ptr())

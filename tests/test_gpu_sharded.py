@@ -65,7 +65,7 @@ def test_two_rank_sharded_map_matches_unsharded(deterministic):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, deterministic)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=280) for _ in procs)
+    res = dict(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
