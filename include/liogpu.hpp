@@ -1,0 +1,74 @@
+// liogpu.hpp -- header-only C++ mirror of the reference's member functions over
+// the C ABI in liogpu.h.  Names follow class mapOptimization (MO =
+// src/liorf/src/mapOptmization.cpp) so that the patched node reads like the
+// original: scan2MapOptimization() MO:1839, transformUpdate() MO:1867.
+// No PCL/ROS dependency: clouds are passed as (pointer, count, stride).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "liogpu.h"
+
+namespace liogpu {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+class ScanToMap {
+public:
+    // transformTobeMapped [roll,pitch,yaw,x,y,z] (MO:171) and isDegenerate (MO:176) live here
+    // exactly like the members they replace.
+    float transformTobeMapped[6] = {0, 0, 0, 0, 0, 0};
+    bool isDegenerate = false;
+    lio_s2m_result last{};
+
+    explicit ScanToMap(const lio_s2m_config* cfg = nullptr)
+    {
+        lio_s2m_config c;
+        if (cfg) c = *cfg; else lio_s2m_default_config(&c);
+        check(lio_s2m_create(&c, &h_), "lio_s2m_create");
+    }
+    ~ScanToMap() { lio_s2m_destroy(h_); }
+    ScanToMap(const ScanToMap&) = delete;
+    ScanToMap& operator=(const ScanToMap&) = delete;
+
+    // kdtreeSurfFromMap->setInputCloud(laserCloudSurfFromMapDS), MO:1846
+    void setInputCloud(const void* pts, size_t n, size_t stride_bytes)
+    {
+        check(lio_s2m_set_map(h_, pts, n, stride_bytes), "lio_s2m_set_map");
+    }
+
+    // The loop MO:1848-1859.  Returns the status: LIO_OK, LIO_TOO_FEW_POINTS (MO:1862-1864: the
+    // caller prints the ROS_WARN) or LIO_TOO_FEW_CORR.  The caller keeps the guards MO:1841-1844
+    // and calls transformUpdate() afterwards (MO:1861).
+    int scan2MapOptimization(const void* laserCloudSurfLastDS, size_t n, size_t stride_bytes)
+    {
+        const int rc = lio_s2m_register(h_, laserCloudSurfLastDS, n, stride_bytes, transformTobeMapped, &last);
+        if (rc < 0) check(rc, "lio_s2m_register");
+        isDegenerate = last.is_degenerate != 0;
+        return rc;
+    }
+
+    // transformUpdate + constraintTransformation, MO:1867-1907
+    void transformUpdate(bool imuAvailable, int imuType, float imuRollInit, float imuPitchInit,
+                         float imuRPYWeight, float rotation_tollerance, float z_tollerance)
+    {
+        lio_transform_update(transformTobeMapped, imuAvailable ? 1 : 0, imuType, imuRollInit, imuPitchInit,
+                             imuRPYWeight, rotation_tollerance, z_tollerance);
+    }
+
+    lio_s2m_handle* handle() { return h_; }
+
+private:
+    static void check(int rc, const char* what)
+    {
+        if (rc < 0) throw Error(rc, std::string(what) + ": " + lio_last_error());
+    }
+    lio_s2m_handle* h_ = nullptr;
+};
+
+}  // namespace liogpu
