@@ -160,6 +160,9 @@ int  lio_s2m_batch_begin(lio_s2m_handle *h);
 int  lio_s2m_batch_iter_partial(lio_s2m_handle *h, double *d_sums /* device, n_scans x 32 */);
 int  lio_s2m_batch_iter_apply(lio_s2m_handle *h, const double *d_sums);
 int  lio_s2m_batch_n_active(lio_s2m_handle *h, int32_t *n_active);
+/* Scans still iterating after applied iteration `iteration` (0-based); waits only for that
+ * iteration, so the caller can keep later iterations enqueued. */
+int  lio_s2m_batch_poll_active(lio_s2m_handle *h, int32_t iteration, int32_t *n_active);
 
 /* transformUpdate + constraintTransformation, MO:1867-1907 (host, fp64 slerp). */
 void lio_transform_update(float pose[6], int32_t imu_available, int32_t imu_type,

@@ -89,7 +89,7 @@ EXPORTS = [
     "lio_s2m_set_global_grid", "lio_s2m_set_shard", "lio_s2m_batch_begin",
     "lio_s2m_batch_iter_partial", "lio_s2m_batch_iter_apply", "lio_s2m_batch_n_active",
     "lio_transform_update", "lio_deskew_default_config", "lio_imu_deskew_info", "lio_deskew",
-    "lio_curvature", "lio_s2m_debug_stamps",
+    "lio_curvature", "lio_s2m_debug_stamps", "lio_s2m_batch_poll_active",
 ]
 
 
@@ -128,6 +128,7 @@ def load_library():
     L.lio_s2m_batch_iter_partial.argtypes = [vp, vp]
     L.lio_s2m_batch_iter_apply.argtypes = [vp, vp]
     L.lio_s2m_batch_n_active.argtypes = [vp, C.POINTER(i32)]
+    L.lio_s2m_batch_poll_active.argtypes = [vp, i32, C.POINTER(i32)]
     L.lio_transform_update.argtypes = [C.POINTER(f32), i32, i32, f32, f32, f32, f32, f32]
     L.lio_transform_update.restype = None
     L.lio_deskew_default_config.argtypes = [C.POINTER(DeskewConfig)]
@@ -276,6 +277,11 @@ class ScanToMap:
 
     def batch_iter_apply(self, d_sums_ptr):
         _check(self.lib.lio_s2m_batch_iter_apply(self.h, C.c_void_p(d_sums_ptr)), "lio_s2m_batch_iter_apply")
+
+    def batch_poll_active(self, iteration):
+        v = C.c_int32()
+        _check(self.lib.lio_s2m_batch_poll_active(self.h, iteration, C.byref(v)), "lio_s2m_batch_poll_active")
+        return v.value
 
     def batch_n_active(self):
         v = C.c_int32()

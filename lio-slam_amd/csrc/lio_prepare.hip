@@ -281,6 +281,7 @@ extern "C" int lio_deskew(const lio_deskew_config* cfg, const void* pts, size_t 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return lio_fail_ext(LIO_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)", hipSuccess);
     HIPCHK(hipSetDevice(cfg->device_id));
+    (void)hipGetLastError();
 
     const int nb = (int)((n + 255) / 256);
     const int nt = do_deskew ? imuPointerCur + 1 : 0;
@@ -338,6 +339,7 @@ extern "C" int lio_curvature(int32_t device_id, const float* range, size_t n, fl
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return lio_fail_ext(LIO_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)", hipSuccess);
     HIPCHK(hipSetDevice(device_id));
+    (void)hipGetLastError();
     DevBuf d_r, d_c, d_p, d_l;
     HIPCHK(d_r.alloc(n * 4)); HIPCHK(d_c.alloc(n * 4));
     if (neighbor_picked) HIPCHK(d_p.alloc(n * 4));

@@ -236,6 +236,7 @@ extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, siz
     if (stride < 12 || (stride & 3)) return lio_fail(LIO_ERR_ARG, "stride_bytes must be >= 12 and a multiple of 4");
     if (n >= (1ull << 25)) return lio_fail(LIO_ERR_CAPACITY, "map too large ((2k+1)^2 x n records must fit a 31-bit offset)");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     auto t0 = std::chrono::steady_clock::now();
     h->has_map = false;
     h->n_map = n;
@@ -343,6 +344,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     if (n_scans < 1) return lio_fail(LIO_ERR_ARG, "n_scans must be >= 1");
     if (stride < 12 || (stride & 3)) return lio_fail(LIO_ERR_ARG, "stride_bytes must be >= 12 and a multiple of 4");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     size_t total = 0, max_n = 0;
     for (int s = 0; s < n_scans; ++s) {
         if (n_pts[s] && !scans[s]) return lio_fail(LIO_ERR_ARG, "null scan pointer");
@@ -473,6 +475,7 @@ extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
     if (!h || !poses) return lio_fail(LIO_ERR_ARG, "null argument");
     if (h->n_scans < 1) return lio_fail(LIO_ERR_ARG, "no batch uploaded");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     HIPCHK(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_scans * 6 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->poses_set = true;
@@ -484,6 +487,7 @@ extern "C" int lio_s2m_set_degeneracy(lio_s2m_handle* h, int32_t scan, const flo
     if (!h || !matP) return lio_fail(LIO_ERR_ARG, "null argument");
     if (scan < 0 || scan >= h->n_scans) return lio_fail(LIO_ERR_ARG, "scan slot out of range");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     LioScanState& st = h->h_state[scan];
     memcpy(st.matP, matP, sizeof(float) * 36);
     st.is_degenerate = is_degenerate;
@@ -526,6 +530,7 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     if (!h->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
     if (h->n_scans < 1 || !h->poses_set) return lio_fail(LIO_ERR_ARG, "batch_upload and batch_set_poses first");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->c, h->d_active, h->stream);
     h->launches_this_run = 0;
     h->ran = true;
@@ -570,10 +575,15 @@ extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
     if (!h || !d_sums) return lio_fail(LIO_ERR_ARG, "null argument");
     if (!h->ran) return lio_fail(LIO_ERR_ARG, "batch_begin first");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();
     LioIterParams P;
     lio_fill_params(h, P, d_sums);
     HIPCHK(hipMemsetAsync(d_sums, 0, (size_t)h->n_scans * LIO_SUMS * sizeof(double), h->stream));
+    const int it = h->launches_this_run;
+    const bool prof = h->cfg.profile != 0 && it < LIO_MAX_ITERS;
+    if (prof) HIPCHK(hipEventRecord(h->ev_beg[it], h->stream));
     lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
+    if (prof) HIPCHK(hipEventRecord(h->ev_end[it], h->stream));
     h->launches_this_run++;
     HIPCHK(hipGetLastError());
     return LIO_OK;
@@ -582,10 +592,27 @@ extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
 extern "C" int lio_s2m_batch_iter_apply(lio_s2m_handle* h, const double* d_sums)
 {
     if (!h || !d_sums) return lio_fail(LIO_ERR_ARG, "null argument");
-    if (!h->ran) return lio_fail(LIO_ERR_ARG, "batch_begin first");
+    if (!h->ran || h->launches_this_run < 1) return lio_fail(LIO_ERR_ARG, "batch_iter_partial first");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();
     lio_launch_apply(h->d_state, h->n_scans, d_sums, h->c, h->d_active, h->stream);
+    // publish the number of still-iterating scans after this iteration (see lio_s2m_batch_poll_active)
+    const int it = h->launches_this_run - 1;
+    if (it < LIO_MAX_ITERS) {
+        HIPCHK(hipMemcpyAsync(&h->h_active[it], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->ev_chk[it], h->stream));
+    }
     HIPCHK(hipGetLastError());
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_batch_poll_active(lio_s2m_handle* h, int32_t iteration, int32_t* n_active)
+{
+    if (!h || !n_active) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (iteration < 0 || iteration >= h->launches_this_run || iteration >= LIO_MAX_ITERS)
+        return lio_fail(LIO_ERR_ARG, "iteration has not been applied");
+    HIPCHK(hipEventSynchronize(h->ev_chk[iteration]));
+    *n_active = h->h_active[iteration];
     return LIO_OK;
 }
 
@@ -593,6 +620,7 @@ extern "C" int lio_s2m_batch_n_active(lio_s2m_handle* h, int32_t* n_active)
 {
     if (!h || !n_active) return lio_fail(LIO_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     HIPCHK(hipMemcpyAsync(&h->h_active[0], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     *n_active = h->h_active[0];
@@ -603,6 +631,7 @@ extern "C" int lio_s2m_batch_sync(lio_s2m_handle* h)
 {
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     return LIO_OK;
@@ -613,6 +642,7 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     if (!h->ran) return lio_fail(LIO_ERR_ARG, "nothing has been run");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     HIPCHK(hipMemcpyAsync(h->h_state.data(), h->d_state, (size_t)h->n_scans * sizeof(LioScanState),
                           hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -682,6 +712,7 @@ extern "C" int lio_s2m_get_correspondences(lio_s2m_handle* h, int32_t scan, uint
     if (h->cfg.record_corr_iter < 0) return lio_fail(LIO_ERR_ARG, "record_corr_iter was not set at create time");
     if (scan < 0 || scan >= h->n_scans) return lio_fail(LIO_ERR_ARG, "scan slot out of range");
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     const size_t off = (size_t)h->h_state[scan].offset, n = (size_t)h->h_state[scan].n_pts;
     if (n == 0) return LIO_OK;
     if (flag) HIPCHK(hipMemcpyAsync(flag, h->d_rec_flag + off, n, hipMemcpyDeviceToHost, h->stream));

@@ -96,7 +96,7 @@ class ShardedRunner:
     solves from the same all-reduced sums.
     """
 
-    def __init__(self, s2m, map_xyz, rank, world, dist, torch, deterministic=False):
+    def __init__(self, s2m, map_xyz, rank, world, dist, torch, deterministic=False, lookahead=1):
         self.s2m, self.rank, self.world, self.dist, self.torch = s2m, rank, world, dist, torch
         self.plan = plan_shards(map_xyz, world)
         self.idx = shard_points(map_xyz, self.plan, rank)
@@ -106,6 +106,7 @@ class ShardedRunner:
         # kernels and the collective share torch's current stream
         s2m.set_stream(torch.cuda.current_stream().cuda_stream)
         self.deterministic = deterministic
+        self.lookahead = lookahead      # iterations enqueued ahead of the all-scans-done check
         self.sums = None
 
     def run(self):
@@ -129,6 +130,9 @@ class ShardedRunner:
                 dist.all_reduce(self.sums, op=dist.ReduceOp.SUM)
             s2m.batch_iter_apply(self.sums.data_ptr())
             iters += 1
-            if s2m.batch_n_active() == 0:                        # MO:1857-1858, every scan
+            # MO:1857-1858 for every scan.  Every rank solves the same sums, so every rank sees the
+            # same count and leaves the loop at the same iteration (the collectives stay matched).
+            chk = it - self.lookahead
+            if chk >= 0 and s2m.batch_poll_active(chk) == 0:
                 break
         return iters
