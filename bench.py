@@ -101,12 +101,13 @@ def main():
     ap.add_argument("--keyframes", type=int, default=200)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--variant", type=int, default=2, help="scan points per thread (1, 2, 4)")
+    ap.add_argument("--variant", type=int, default=1, help="scan points per thread (1, 2, 4)")
     ap.add_argument("--latency", action="store_true", help="also time single-scan registrations")
     ap.add_argument("--case-cache", default="", help="npz path: load the synthetic case if present, else generate and save")
     ap.add_argument("--lds", type=int, default=0)
     ap.add_argument("--sort", type=int, default=1)
     ap.add_argument("--celldiv", type=int, default=2)
+    ap.add_argument("--xcd", type=int, default=1)
     args = ap.parse_args()
 
     import torch
@@ -166,7 +167,7 @@ def main():
 
     # -------------------------------------------------------------- engine
     s2m = pkg.ScanToMap(device_id=local_rank, profile=1, lookahead=0, kernel_variant=args.variant,
-                        use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv)
+                        use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd)
     if world > 1:
         runner = multi.ShardedRunner(s2m, map_xyz, rank, world, dist, torch)
     else:

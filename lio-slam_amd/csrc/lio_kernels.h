@@ -22,6 +22,7 @@ struct LioIterParams {
     double* partials;              // [scan][max_blk][LIO_SUMS]
     unsigned* arrive;              // [scan] arrival counters
     int max_blk;
+    int xcd_remap;                 // 1 = XCD-aware workgroup order
     int* n_active;                 // scans still iterating (device counter)
     double* sums_out;              // sharded mode: [scan][LIO_SUMS]; nullptr = solve in place
     unsigned char* rec_flag;       // optional correspondence record (iteration c.record_iter)

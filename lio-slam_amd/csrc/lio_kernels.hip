@@ -556,6 +556,9 @@ LIO_DEV void lio_knn_lds(const float4* s_pts, const int* s_cell, int rx1, int ry
 __constant__ int c_pair_a[32] = { 0,0,0,0,0,0, 1,1,1,1,1, 2,2,2,2, 3,3,3, 4,4, 5,  0,1,2,3,4,5, 7, 0,0,0,0 };
 __constant__ int c_pair_b[32] = { 0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5, 4,5, 5,  6,6,6,6,6,6, 7, 0,0,0,0 };
 
+#ifndef LIO_MIN_WAVES
+#define LIO_MIN_WAVES 4      // waves per SIMD asked of the register allocator (<= 128 VGPRs)
+#endif
 #define LIO_LDS_PTS   2048     // staged map points per workgroup (32 KiB)
 #define LIO_LDS_CELLS 1536     // staged run offsets (6 KiB)
 #define LIO_LDS_ROWS  256      // (y,z) rows of a region
@@ -567,7 +570,7 @@ __constant__ int c_pair_b[32] = { 0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5, 4,5, 5
 // candidates from LDS.  Regions that do not fit fall back to the global form;
 // both forms visit the same candidate set, so results are identical.
 template <int PPT, bool STAGE>
-__global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
+__global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIterParams P)
 {
     __shared__ __attribute__((aligned(16))) float s_rows[LIO_BLOCK][8];   // [arz ary arx cx cy cz | -cw | accepted]
     __shared__ double s_part[8][28];
@@ -580,11 +583,19 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_s2m_iterate(LioIterParams P)
     __shared__ int s_box[8];
     __shared__ int s_scan4[4];
 
-    const LioBlockDesc bd = P.blocks[blockIdx.x];
+    // XCD-aware order (speed only): consecutive workgroup ids are dealt round-robin over the 8
+    // XCDs, each with a private L2.  Give every XCD one contiguous eighth of the scan-major,
+    // tile-sorted work list so that the map rows it streams stay in ITS L2.
+    int wg = blockIdx.x;
+    if (P.xcd_remap) {
+        const int n8 = gridDim.x >> 3;                     // full groups of 8
+        if (wg < n8 * 8) wg = (wg & 7) * n8 + (wg >> 3);
+    }
+    const LioBlockDesc bd = P.blocks[wg];
     LioScanState* st = &P.state[bd.scan];
     if (st->done) return;                                  // workgroup-uniform
     // diagnostic phase clock (P.stamps is null outside profiling experiments)
-    long long* stamp = P.stamps ? P.stamps + ((size_t)blockIdx.x * (LIO_BLOCK / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
+    long long* stamp = P.stamps ? P.stamps + ((size_t)wg * (LIO_BLOCK / 64) + (threadIdx.x >> 6)) * 8 : nullptr;
 #define LIO_STAMP(k) do { if (stamp && (threadIdx.x & 63) == 0) stamp[k] = (long long)__builtin_readcyclecounter(); } while (0)
     LIO_STAMP(0);
 

@@ -138,6 +138,7 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->lookahead = -1;
     c->use_lds = 0;
     c->cell_div = 2;
+    c->xcd_remap = 1;
     c->sort_scan = 1;
 }
 
@@ -515,6 +516,7 @@ static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_ou
     P.partials = h->d_partials;
     P.arrive = h->d_arrive;
     P.max_blk = h->max_blk;
+    P.xcd_remap = h->cfg.xcd_remap;
     P.n_active = h->d_active;
     P.sums_out = sums_out;
     const bool rec = h->cfg.record_corr_iter >= 0;
