@@ -143,24 +143,50 @@ def main():
     # ---------------------------------------------------------------- data
     B = args.batch * world
     t0 = time.time()
-    if args.case_cache and os.path.exists(args.case_cache):
-        z = np.load(args.case_cache)
-        map_xyz, poses0, poses_true = z["map"], z["poses0"], z["poses_true"]
-        cat, lens = z["scans"], z["lens"]
-        offs = np.concatenate([[0], np.cumsum(lens)])
-        scans = [np.ascontiguousarray(cat[offs[i]:offs[i + 1]]) for i in range(len(lens))]
-        assert len(scans) == B, "case cache was generated for another batch size"
-    else:
+    def generate():
+        if args.case_cache and os.path.exists(args.case_cache):
+            z = np.load(args.case_cache)
+            offs = np.concatenate([[0], np.cumsum(z["lens"])])
+            sc = [np.ascontiguousarray(z["scans"][offs[i]:offs[i + 1]]) for i in range(len(z["lens"]))]
+            assert len(sc) == B, "case cache was generated for another batch size"
+            return z["map"], sc, z["poses0"], z["poses_true"]
         case = synth.make_case(args.sensor, n_keyframes=args.keyframes, seed=synth.BASE_SEED, n_queries=B,
                                device=f"cuda:{local_rank}",
                                progress=lambda k, n: log(f"map keyframe {k}/{n}"))
-        map_xyz = case["map"]
-        scans = [q["scan"] for q in case["queries"]]
-        poses0 = np.stack([q["pose_init"] for q in case["queries"]]).astype(np.float32)
-        poses_true = np.stack([q["pose_true"] for q in case["queries"]])
-        if args.case_cache and rank == 0:
-            np.savez(args.case_cache, map=map_xyz, poses0=poses0, poses_true=poses_true,
-                     scans=np.concatenate(scans), lens=np.array([len(s) for s in scans]))
+        sc = [q["scan"] for q in case["queries"]]
+        p0 = np.stack([q["pose_init"] for q in case["queries"]]).astype(np.float32)
+        pt = np.stack([q["pose_true"] for q in case["queries"]]).astype(np.float32)
+        if args.case_cache:
+            np.savez(args.case_cache, map=case["map"], poses0=p0, poses_true=pt,
+                     scans=np.concatenate(sc), lens=np.array([len(x) for x in sc]))
+        return case["map"], sc, p0, pt
+
+    if world == 1:
+        map_xyz, scans, poses0, poses_true = generate()
+    else:
+        # rank 0 generates, everyone receives the SAME bytes (the ranks must agree on the map
+        # shards and on every convergence decision, or their collectives would not match)
+        if rank == 0:
+            map_xyz, scans, poses0, poses_true = generate()
+            lens = np.array([len(x) for x in scans], np.int64)
+            hdr = torch.tensor([len(map_xyz), int(lens.sum())], dtype=torch.int64, device="cuda")
+        else:
+            hdr = torch.zeros(2, dtype=torch.int64, device="cuda")
+        dist.broadcast(hdr, 0)
+        n_map, n_pts = int(hdr[0]), int(hdr[1])
+
+        def bcast(arr, shape, dtype):
+            t = torch.from_numpy(np.ascontiguousarray(arr)).cuda() if rank == 0 else torch.zeros(shape, dtype=dtype, device="cuda")
+            dist.broadcast(t, 0)
+            return t.cpu().numpy()
+
+        map_xyz = bcast(map_xyz if rank == 0 else None, (n_map, 3), torch.float32)
+        cat = bcast(np.concatenate(scans) if rank == 0 else None, (n_pts, 3), torch.float32)
+        lens = bcast(lens if rank == 0 else None, (B,), torch.int64)
+        poses0 = bcast(poses0 if rank == 0 else None, (B, 6), torch.float32)
+        poses_true = bcast(poses_true if rank == 0 else None, (B, 6), torch.float32)
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        scans = [np.ascontiguousarray(cat[offs[i]:offs[i + 1]]) for i in range(B)]
     n_s = np.array([len(s) for s in scans])
     log(f"data: N_m={len(map_xyz)} N_s mean={n_s.mean():.0f} min={n_s.min()} max={n_s.max()} "
         f"B={B} gen {time.time() - t0:.1f}s")
