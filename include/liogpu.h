@@ -209,6 +209,25 @@ int  lio_deskew(const lio_deskew_config *cfg, const void *pts, size_t n, size_t 
 int  lio_curvature(int32_t device_id, const float *range, size_t n, float *curvature,
                    int32_t *neighbor_picked, int32_t *label);
 
+/* ------------------------------------------------ local-map assembly (feeders) */
+/* pcl::VoxelGrid<PointXYZI>::filter as used by downsampleCurrentScan MO:1605-1611
+ * (downSizeFilterSurf, leaf = mappingSurfLeafSize) and MO:1581-1583: centroid per
+ * voxel (x, y, z and intensity), output in ascending voxel index.  Records: x,y,z
+ * @0,4,8 and intensity @16.  Returns LIO_OK, or 1 when PCL would pass the cloud
+ * through unfiltered ("Leaf size is too small", voxel index overflow). */
+int  lio_voxel_grid(int32_t device_id, const void *pts, size_t n, size_t stride_bytes, float leaf,
+                    void *out, size_t out_stride_bytes, size_t *n_out);
+
+/* extractCloud MO:1556-1588: laserCloudSurfFromMap = sum over the nearby keyframes of
+ * transformPointCloud(surfCloudKeyFrames[i], cloudKeyPoses6D[i]) (MO:849-868), then
+ * VoxelGrid(surroundingKeyframeMapLeafSize) -> laserCloudSurfFromMapDS.  poses are
+ * [roll,pitch,yaw,x,y,z] per keyframe.  If h != NULL the result becomes h's resident map
+ * (replaces lio_s2m_set_map, no round trip through the host); `out` (may be NULL) receives
+ * the downsampled map as PointXYZI-compatible records. */
+int  lio_assemble_map(lio_s2m_handle *h, int32_t device_id, int32_t n_keyframes, const void *const *clouds,
+                      const size_t *n_pts, size_t stride_bytes, const float *poses, float leaf,
+                      void *out, size_t out_stride_bytes, size_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

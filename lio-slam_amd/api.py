@@ -89,7 +89,7 @@ EXPORTS = [
     "lio_s2m_set_global_grid", "lio_s2m_set_shard", "lio_s2m_batch_begin",
     "lio_s2m_batch_iter_partial", "lio_s2m_batch_iter_apply", "lio_s2m_batch_n_active",
     "lio_transform_update", "lio_deskew_default_config", "lio_imu_deskew_info", "lio_deskew",
-    "lio_curvature", "lio_s2m_debug_stamps", "lio_s2m_batch_poll_active",
+    "lio_curvature", "lio_s2m_debug_stamps", "lio_s2m_batch_poll_active", "lio_voxel_grid", "lio_assemble_map",
 ]
 
 
@@ -139,6 +139,9 @@ def load_library():
                              C.POINTER(sz)]
     L.lio_curvature.argtypes = [i32, vp, sz, vp, vp, vp]
     L.lio_s2m_debug_stamps.argtypes = [vp, vp, sz]
+    L.lio_voxel_grid.argtypes = [i32, vp, sz, sz, f32, vp, sz, C.POINTER(sz)]
+    L.lio_assemble_map.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(f32), f32, vp, sz,
+                                   C.POINTER(sz)]
     _LIB = L
     return L
 
@@ -355,3 +358,43 @@ def curvature(rng, device_id=0):
     _check(load_library().lio_curvature(device_id, r.ctypes.data, len(r), curv.ctypes.data,
                                         picked.ctypes.data, label.ctypes.data), "lio_curvature")
     return curv, picked, label
+
+
+def _as_xyzi_records(a):
+    """[n,4] (x,y,z,intensity) float32 -> pcl::PointXYZI records [n,8] (32-byte stride)."""
+    a = np.ascontiguousarray(a, np.float32)
+    rec = np.zeros((len(a), 8), np.float32)
+    rec[:, :3] = a[:, :3]
+    rec[:, 3] = 1.0
+    rec[:, 4] = a[:, 3]
+    return rec
+
+
+def _from_records(rec, n):
+    return np.concatenate([rec[:n, :3], rec[:n, 4:5]], axis=1).copy()
+
+
+# downsampleCurrentScan, MO:1605-1611 (pcl::VoxelGrid)
+def voxel_grid(xyzi, leaf, device_id=0):
+    rec = _as_xyzi_records(xyzi)
+    out = np.zeros_like(rec)
+    n_out = C.c_size_t()
+    rc = _check(load_library().lio_voxel_grid(device_id, rec.ctypes.data, len(rec), 32, leaf, out.ctypes.data, 32,
+                                              C.byref(n_out)), "lio_voxel_grid")
+    return _from_records(out, n_out.value), rc
+
+
+# extractCloud, MO:1556-1588
+def assemble_map(clouds_xyzi, poses, leaf, s2m=None, device_id=0, want_output=True):
+    recs = [_as_xyzi_records(c) for c in clouds_xyzi]
+    n = len(recs)
+    ptrs = (C.c_void_p * max(n, 1))(*[r.ctypes.data for r in recs])
+    npts = (C.c_size_t * max(n, 1))(*[len(r) for r in recs])
+    p = np.ascontiguousarray(poses, np.float32).reshape(n, 6)
+    total = sum(len(r) for r in recs)
+    out = np.zeros((max(total, 1), 8), np.float32) if want_output else None
+    n_out = C.c_size_t()
+    rc = _check(load_library().lio_assemble_map(s2m.h if s2m is not None else None, device_id, n, ptrs, npts, 32,
+                                                _f32p(p), leaf, out.ctypes.data if want_output else None, 32,
+                                                C.byref(n_out)), "lio_assemble_map")
+    return (_from_records(out, n_out.value) if want_output else None), n_out.value, rc

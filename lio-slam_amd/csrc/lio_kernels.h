@@ -48,3 +48,5 @@ void lio_launch_scan_tile_sort(const void* stage, size_t stride, int total_pts,
                                const LioScanState* st, const LioScanTiles* tiles, int n_keys,
                                int* key_of, int* key_count, int* key_start, int* tile_sums,
                                int* tmp_idx, int* perm, float* x, float* y, float* z, hipStream_t s);
+void lio_launch_exclusive_scan(const int* in, int n, int* tile_sums, int* out, hipStream_t s);
+void lio_launch_xyzi4_to_soa(const float4* src, int n, float* x, float* y, float* z, float4* xyz4, hipStream_t s);

@@ -48,6 +48,16 @@ __global__ void k_aos_to_soa(const unsigned char* __restrict__ src, size_t strid
     if (xyz4) xyz4[i] = make_float4(a, b, c, 0.0f);
 }
 
+__global__ void k_xyzi4_to_soa(const float4* __restrict__ src, int n, float* __restrict__ x, float* __restrict__ y,
+                               float* __restrict__ z, float4* __restrict__ xyz4)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = src[i];
+    x[i] = v.x; y[i] = v.y; z[i] = v.z;
+    xyz4[i] = make_float4(v.x, v.y, v.z, 0.0f);
+}
+
 // ---------------------------------------------------------------- map build
 // bbox[0..2] = min (ordered uint), bbox[3..5] = max
 __global__ void k_map_bbox(const float* __restrict__ x, const float* __restrict__ y,
@@ -871,7 +881,7 @@ void lio_launch_map_bbox(const float* x, const float* y, const float* z, int n, 
     hipLaunchKernelGGL(k_map_bbox, dim3(blocks), dim3(256), 0, s, x, y, z, n, bbox);
 }
 
-static void lio_exclusive_scan(const int* in, int n, int* tile_sums, int* out, hipStream_t s)
+void lio_launch_exclusive_scan(const int* in, int n, int* tile_sums, int* out, hipStream_t s)
 {
     const int n_tiles = (n + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE;
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, s, in, n, tile_sums);
@@ -887,13 +897,13 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
     // cell-sorted copy (1x): used by the LDS-staged variant
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
     hipLaunchKernelGGL(k_map_cell_count, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, cell_count);
-    lio_exclusive_scan(cell_count, g.n_cells, tile_sums, cell_start, s);
+    lio_launch_exclusive_scan(cell_count, g.n_cells, tile_sums, cell_start, s);
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);   // reused as the fill cursor
     hipLaunchKernelGGL(k_map_scatter, dim3(nb), dim3(256), 0, s, x, y, z, n, cell_of, cell_start, cell_count, sorted);
     // replicated neighbourhood rows (9x): used by the default candidate scan
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
     hipLaunchKernelGGL(k_map_nbr_count, dim3(nb), dim3(256), 0, s, g, cell_of, n, cell_count);
-    lio_exclusive_scan(cell_count, g.n_cells, tile_sums, nbr_start, s);
+    lio_launch_exclusive_scan(cell_count, g.n_cells, tile_sums, nbr_start, s);
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
     hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, nbr_start, cell_count, nbr_pts);
 }
@@ -952,4 +962,10 @@ void lio_launch_scan_tile_sort(const void* stage, size_t stride, int total_pts,
     hipLaunchKernelGGL(k_scan_tile_ranksort, dim3((n_keys + 3) / 4), dim3(256), 0, s, key_start, n_keys, tmp_idx, perm);
     hipLaunchKernelGGL(k_scan_gather_sorted, dim3(nb), dim3(256), 0, s, (const unsigned char*)stage, stride,
                        total_pts, perm, x, y, z);
+}
+
+void lio_launch_xyzi4_to_soa(const float4* src, int n, float* x, float* y, float* z, float4* xyz4, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_xyzi4_to_soa, dim3((n + 255) / 256), dim3(256), 0, s, src, n, x, y, z, xyz4);
 }

@@ -1,0 +1,376 @@
+// lio_mapbuild.hip -- the feeders of the registration path:
+//   K6 transformPointCloud           MO:849-868
+//   K7 pcl::VoxelGrid centroid filter MO:1605-1611 (scan), MO:1581-1583 (local map)
+//   extractCloud = sum of K6 over the nearby keyframes, then K7   MO:1556-1588
+// MO = /root/reference/src/liorf/src/mapOptmization.cpp.  -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/liogpu.h"
+#include "lio_kernels.h"
+#include "lio_device_math.h"
+
+int lio_fail_ext(int code, const char* what, hipError_t e);                    // liogpu_api.hip
+int lio_s2m_set_map_device_xyzi(lio_s2m_handle* h, const float4* d_xyzi, size_t n);   // liogpu_api.hip
+
+#define HIPCHK(expr)                                                              \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) return lio_fail_ext(LIO_ERR_HIP, #expr, _e);        \
+    } while (0)
+
+struct LioKfDesc {       // one keyframe cloud inside the concatenated staging buffer
+    int first;           // first point in the concatenation
+    int n;
+    float T[12];         // pclPointToAffine3f of its pose (MO:856), filled on the device
+};
+
+// pose [roll,pitch,yaw,x,y,z] -> 3x4 transform, same trig definition as the GN loop
+__global__ void k_kf_transforms(LioKfDesc* __restrict__ kf, const float* __restrict__ poses, int n_kf)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_kf) return;
+    float pose[6], T[12], trig[6];
+    for (int j = 0; j < 6; ++j) pose[j] = poses[k * 6 + j];
+    lio_pose_to_transform(pose, T, trig);
+    for (int j = 0; j < 12; ++j) kf[k].T[j] = T[j];
+}
+
+// K6: AoS records (x,y,z @0,4,8; intensity @16) of every keyframe -> world-frame float4 (x,y,z,i)
+__global__ __launch_bounds__(256) void k_transform_clouds(const unsigned char* __restrict__ src, size_t stride,
+                                                          const LioKfDesc* __restrict__ kf,
+                                                          const int2* __restrict__ chunks /* (kf, first) */,
+                                                          float4* __restrict__ dst)
+{
+    const int2 c = chunks[blockIdx.x];
+    const LioKfDesc d = kf[c.x];
+    const int li = c.y + (int)threadIdx.x;
+    if (li >= d.n) return;
+    const int gi = d.first + li;
+    const float* p = reinterpret_cast<const float*>(src + (size_t)gi * stride);
+    const float x = p[0], y = p[1], z = p[2];
+    dst[gi] = make_float4(d.T[0] * x + d.T[1] * y + d.T[2]  * z + d.T[3],
+                          d.T[4] * x + d.T[5] * y + d.T[6]  * z + d.T[7],
+                          d.T[8] * x + d.T[9] * y + d.T[10] * z + d.T[11], p[4]);     // MO:861-864
+}
+
+__global__ void k_aos_to_xyzi4(const unsigned char* __restrict__ src, size_t stride, int n, float4* __restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = reinterpret_cast<const float*>(src + (size_t)i * stride);
+    dst[i] = make_float4(p[0], p[1], p[2], p[4]);
+}
+
+__device__ __forceinline__ unsigned lio_f2ord2(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// getMinMax3D (PCL): bbox[0..2] = min, bbox[3..5] = max as order-preserving uints
+__global__ void k_vox_bbox(const float4* __restrict__ p, int n, unsigned* __restrict__ bbox)
+{
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 v = p[i];
+        mn[0] = fminf(mn[0], v.x); mx[0] = fmaxf(mx[0], v.x);
+        mn[1] = fminf(mn[1], v.y); mx[1] = fmaxf(mx[1], v.y);
+        mn[2] = fminf(mn[2], v.z); mx[2] = fmaxf(mx[2], v.z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(&bbox[a], lio_f2ord2(mn[a])); atomicMax(&bbox[3 + a], lio_f2ord2(mx[a])); }
+}
+
+struct LioVoxGrid { float inv; int min_b0, min_b1, min_b2, mul1, mul2, n_keys; };
+
+// voxel index of pcl::VoxelGrid: x-fastest over the cloud's own bounding box
+__global__ void k_vox_keys(LioVoxGrid g, const float4* __restrict__ p, int n, int* __restrict__ key_of,
+                           int* __restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = p[i];
+    const int i0 = (int)(floorf(v.x * g.inv) - (float)g.min_b0);
+    const int i1 = (int)(floorf(v.y * g.inv) - (float)g.min_b1);
+    const int i2 = (int)(floorf(v.z * g.inv) - (float)g.min_b2);
+    const int key = i0 + i1 * g.mul1 + i2 * g.mul2;
+    key_of[i] = key;
+    atomicAdd(&count[key], 1);
+}
+
+__global__ void k_vox_scatter(const int* __restrict__ key_of, int n, const int* __restrict__ start,
+                              int* __restrict__ fill, int* __restrict__ tmp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = key_of[i];
+    tmp[start[k] + atomicAdd(&fill[k], 1)] = i;
+}
+
+__global__ void k_vox_flags(const int* __restrict__ start, int n_keys, int* __restrict__ flag)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_keys) flag[k] = (start[k + 1] > start[k]) ? 1 : 0;
+}
+
+__global__ void k_vox_list(const int* __restrict__ start, const int* __restrict__ rank, int n_keys,
+                           int* __restrict__ list)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_keys && start[k + 1] > start[k]) list[rank[k]] = k;
+}
+
+// One wave per occupied voxel: order its points by input index (rank sort in LDS), stage them in
+// LDS, then one lane adds them up in that order in fp32 and divides by the count (PCL's
+// CentroidPoint accumulators).  Output position = rank of the voxel (ascending voxel index).
+#define LIO_VOX_CAP 512
+__global__ __launch_bounds__(256) void k_vox_centroid(const float4* __restrict__ p, const int* __restrict__ start,
+                                                      const int* __restrict__ list, int n_out,
+                                                      const int* __restrict__ tmp, float4* __restrict__ out)
+{
+    __shared__ int s_idx[4][LIO_VOX_CAP];
+    __shared__ __attribute__((aligned(16))) float4 s_pt[4][LIO_VOX_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int o = blockIdx.x * 4 + wave;
+    if (o >= n_out) return;
+    const int key = list[o];
+    const int b = start[key], n = start[key + 1] - b;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+    if (n <= LIO_VOX_CAP) {
+        for (int j = lane; j < n; j += 64) s_idx[wave][j] = tmp[b + j];
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < n; j += 64) {
+            const int v = s_idx[wave][j];
+            int r = 0;
+            for (int i = 0; i < n; ++i) r += (s_idx[wave][i] < v) ? 1 : 0;
+            s_pt[wave][r] = p[v];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0)
+            for (int j = 0; j < n; ++j) {
+                const float4 v = s_pt[wave][j];
+                sx += v.x; sy += v.y; sz += v.z; si += v.w;
+            }
+    } else {
+        // oversized voxel: repeatedly pick the smallest input index above the previous one
+        int prev = -1;
+        for (int j = 0; j < n; ++j) {
+            int best = 0x7fffffff;
+            for (int i = lane; i < n; i += 64) { const int v = tmp[b + i]; if (v > prev && v < best) best = v; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off));
+            prev = best;
+            if (lane == 0) { const float4 v = p[best]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
+        }
+    }
+    if (lane == 0) {
+        const float cnt = (float)n;
+        out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+    }
+}
+
+__global__ void k_xyzi4_to_aos(const float4* __restrict__ src, int n, unsigned char* __restrict__ dst, size_t stride)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = src[i];
+    float* o = reinterpret_cast<float*>(dst + (size_t)i * stride);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = 1.0f; o[4] = v.w;
+}
+
+namespace {
+struct Buf {
+    void* p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <typename T> T* as() { return (T*)p; }
+};
+
+float ord2f(unsigned u)
+{
+    const unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+// K7 on a device-resident float4 cloud.  *d_out receives a freshly allocated device array.
+// Returns LIO_OK, or 1 when PCL would pass the cloud through (voxel index overflow).
+int voxel_grid_device(const float4* d_in, int n, float leaf, Buf& out, int* n_out, hipStream_t s)
+{
+    *n_out = 0;
+    if (n == 0) return LIO_OK;
+    Buf bbox;
+    HIPCHK(bbox.alloc(6 * sizeof(unsigned)));
+    const unsigned init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+    HIPCHK(hipMemcpyAsync(bbox.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+    int nbb = (n + 255) / 256; if (nbb > 2048) nbb = 2048;
+    hipLaunchKernelGGL(k_vox_bbox, dim3(nbb), dim3(256), 0, s, d_in, n, bbox.as<unsigned>());
+    unsigned hb[6];
+    HIPCHK(hipMemcpyAsync(hb, bbox.p, sizeof(hb), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) { mn[a] = ord2f(hb[a]); mx[a] = ord2f(hb[3 + a]); }
+    const float inv = 1.0f / leaf;
+    const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1,
+                    dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > 2147483647LL) {                       // "Leaf size is too small": PCL copies the input
+        HIPCHK(out.alloc(sizeof(float4) * (size_t)n));
+        HIPCHK(hipMemcpyAsync(out.p, d_in, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, s));
+        *n_out = n;
+        return 1;
+    }
+    LioVoxGrid g;
+    g.inv = inv;
+    g.min_b0 = (int)floorf(mn[0] * inv); g.min_b1 = (int)floorf(mn[1] * inv); g.min_b2 = (int)floorf(mn[2] * inv);
+    const int d0 = (int)floorf(mx[0] * inv) - g.min_b0 + 1, d1 = (int)floorf(mx[1] * inv) - g.min_b1 + 1,
+              d2 = (int)floorf(mx[2] * inv) - g.min_b2 + 1;
+    g.mul1 = d0; g.mul2 = d0 * d1;
+    const long long n_keys_ll = (long long)d0 * d1 * d2;
+    if (n_keys_ll > (1LL << 29)) return lio_fail_ext(LIO_ERR_CAPACITY, "voxel grid has more than 2^29 voxels", hipSuccess);
+    g.n_keys = (int)n_keys_ll;
+    Buf key_of, count, start, rank, tiles, tmp, list;
+    HIPCHK(key_of.alloc(sizeof(int) * (size_t)n));
+    HIPCHK(tmp.alloc(sizeof(int) * (size_t)n));
+    HIPCHK(count.alloc(sizeof(int) * (size_t)g.n_keys));
+    HIPCHK(start.alloc(sizeof(int) * ((size_t)g.n_keys + 1)));
+    HIPCHK(rank.alloc(sizeof(int) * ((size_t)g.n_keys + 1)));
+    HIPCHK(tiles.alloc(sizeof(int) * ((size_t)lio_scan_tiles(g.n_keys) + 1)));
+    const int nb = (n + 255) / 256, nk = (g.n_keys + 255) / 256;
+    HIPCHK(hipMemsetAsync(count.p, 0, sizeof(int) * (size_t)g.n_keys, s));
+    hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, g, d_in, n, key_of.as<int>(), count.as<int>());
+    lio_launch_exclusive_scan(count.as<int>(), g.n_keys, tiles.as<int>(), start.as<int>(), s);
+    HIPCHK(hipMemsetAsync(count.p, 0, sizeof(int) * (size_t)g.n_keys, s));
+    hipLaunchKernelGGL(k_vox_scatter, dim3(nb), dim3(256), 0, s, key_of.as<int>(), n, start.as<int>(), count.as<int>(), tmp.as<int>());
+    hipLaunchKernelGGL(k_vox_flags, dim3(nk), dim3(256), 0, s, start.as<int>(), g.n_keys, count.as<int>());
+    lio_launch_exclusive_scan(count.as<int>(), g.n_keys, tiles.as<int>(), rank.as<int>(), s);
+    int no = 0;
+    HIPCHK(hipMemcpyAsync(&no, rank.as<int>() + g.n_keys, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(list.alloc(sizeof(int) * (size_t)(no ? no : 1)));
+    HIPCHK(out.alloc(sizeof(float4) * (size_t)(no ? no : 1)));
+    hipLaunchKernelGGL(k_vox_list, dim3(nk), dim3(256), 0, s, start.as<int>(), rank.as<int>(), g.n_keys, list.as<int>());
+    if (no)
+        hipLaunchKernelGGL(k_vox_centroid, dim3((no + 3) / 4), dim3(256), 0, s, d_in, start.as<int>(), list.as<int>(), no,
+                           tmp.as<int>(), out.as<float4>());
+    HIPCHK(hipStreamSynchronize(s));       // temporaries are freed on return
+    HIPCHK(hipGetLastError());
+    *n_out = no;
+    return LIO_OK;
+}
+
+int copy_out(const float4* d_pts, int n, void* out, size_t out_stride, hipStream_t s)
+{
+    if (!out || n == 0) return LIO_OK;
+    Buf aos;
+    HIPCHK(aos.alloc((size_t)n * out_stride));
+    HIPCHK(hipMemsetAsync(aos.p, 0, (size_t)n * out_stride, s));
+    hipLaunchKernelGGL(k_xyzi4_to_aos, dim3((n + 255) / 256), dim3(256), 0, s, d_pts, n, aos.as<unsigned char>(), out_stride);
+    HIPCHK(hipMemcpyAsync(out, aos.p, (size_t)n * out_stride, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return LIO_OK;
+}
+
+int check_device(int device_id)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return lio_fail_ext(LIO_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)", hipSuccess);
+    HIPCHK(hipSetDevice(device_id));
+    (void)hipGetLastError();
+    return LIO_OK;
+}
+}  // namespace
+
+extern "C" int lio_voxel_grid(int32_t device_id, const void* pts, size_t n, size_t stride, float leaf,
+                              void* out, size_t out_stride, size_t* n_out)
+{
+    if (!n_out || (n && (!pts || !out))) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
+    if (stride < 20 || (stride & 3) || out_stride < 20 || (out_stride & 3) || !(leaf > 0.0f))
+        return lio_fail_ext(LIO_ERR_ARG, "strides must be >= 20 and multiples of 4, leaf > 0", hipSuccess);
+    if (n > 0x7fffffffull - 1024) return lio_fail_ext(LIO_ERR_CAPACITY, "cloud too large", hipSuccess);
+    *n_out = 0;
+    if (n == 0) return LIO_OK;
+    int rc = check_device(device_id);
+    if (rc != LIO_OK) return rc;
+    hipStream_t s = nullptr;
+    Buf raw, xyzi, ds;
+    HIPCHK(raw.alloc(n * stride));
+    HIPCHK(xyzi.alloc(n * sizeof(float4)));
+    HIPCHK(hipMemcpyAsync(raw.p, pts, n * stride, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_aos_to_xyzi4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw.as<unsigned char>(), stride, (int)n, xyzi.as<float4>());
+    int no = 0;
+    rc = voxel_grid_device(xyzi.as<float4>(), (int)n, leaf, ds, &no, s);
+    if (rc < 0) return rc;
+    const int rc2 = copy_out(ds.as<float4>(), no, out, out_stride, s);
+    if (rc2 < 0) return rc2;
+    *n_out = (size_t)no;
+    return rc;
+}
+
+extern "C" int lio_assemble_map(lio_s2m_handle* h, int32_t device_id, int32_t n_kf, const void* const* clouds,
+                                const size_t* n_pts, size_t stride, const float* poses, float leaf,
+                                void* out, size_t out_stride, size_t* n_out)
+{
+    if (!clouds || !n_pts || !poses || n_kf < 0) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
+    if (stride < 20 || (stride & 3) || (out && (out_stride < 20 || (out_stride & 3))) || !(leaf > 0.0f))
+        return lio_fail_ext(LIO_ERR_ARG, "strides must be >= 20 and multiples of 4, leaf > 0", hipSuccess);
+    int rc = check_device(device_id);
+    if (rc != LIO_OK) return rc;
+    size_t total = 0;
+    std::vector<LioKfDesc> kf((size_t)n_kf);
+    std::vector<int2> chunks;
+    for (int k = 0; k < n_kf; ++k) {
+        if (n_pts[k] && !clouds[k]) return lio_fail_ext(LIO_ERR_ARG, "null keyframe cloud", hipSuccess);
+        kf[k].first = (int)total; kf[k].n = (int)n_pts[k];
+        for (size_t b = 0; b < n_pts[k]; b += 256) chunks.push_back(make_int2(k, (int)b));
+        total += n_pts[k];
+    }
+    if (total > 0x7fffffffull - 1024) return lio_fail_ext(LIO_ERR_CAPACITY, "too many points", hipSuccess);
+    if (n_out) *n_out = 0;
+    hipStream_t s = nullptr;
+    Buf raw, d_kf, d_poses, d_chunks, world, ds;
+    HIPCHK(raw.alloc(total * stride));
+    HIPCHK(world.alloc(total * sizeof(float4)));
+    HIPCHK(d_kf.alloc(sizeof(LioKfDesc) * (size_t)(n_kf ? n_kf : 1)));
+    HIPCHK(d_poses.alloc(sizeof(float) * 6 * (size_t)(n_kf ? n_kf : 1)));
+    HIPCHK(d_chunks.alloc(sizeof(int2) * (chunks.size() ? chunks.size() : 1)));
+    for (int k = 0; k < n_kf; ++k)
+        if (n_pts[k])
+            HIPCHK(hipMemcpyAsync(raw.as<unsigned char>() + (size_t)kf[k].first * stride, clouds[k], n_pts[k] * stride,
+                                  hipMemcpyHostToDevice, s));
+    if (n_kf) {
+        HIPCHK(hipMemcpyAsync(d_kf.p, kf.data(), sizeof(LioKfDesc) * (size_t)n_kf, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_poses.p, poses, sizeof(float) * 6 * (size_t)n_kf, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_kf_transforms, dim3((n_kf + 63) / 64), dim3(64), 0, s, d_kf.as<LioKfDesc>(), d_poses.as<float>(), n_kf);
+    }
+    if (!chunks.empty()) {
+        HIPCHK(hipMemcpyAsync(d_chunks.p, chunks.data(), sizeof(int2) * chunks.size(), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_transform_clouds, dim3((unsigned)chunks.size()), dim3(256), 0, s, raw.as<unsigned char>(), stride,
+                           d_kf.as<LioKfDesc>(), d_chunks.as<int2>(), world.as<float4>());
+    }
+    HIPCHK(hipStreamSynchronize(s));       // kf / chunks are stack vectors
+    int no = 0;
+    rc = voxel_grid_device(world.as<float4>(), (int)total, leaf, ds, &no, s);
+    if (rc < 0) return rc;
+    if (h) {                               // install as the resident local map without leaving the device
+        const int rc3 = lio_s2m_set_map_device_xyzi(h, ds.as<float4>(), (size_t)no);
+        if (rc3 != LIO_OK) return rc3;
+    }
+    const int rc2 = copy_out(ds.as<float4>(), no, out, out_stride, s);
+    if (rc2 < 0) return rc2;
+    if (n_out) *n_out = (size_t)no;
+    return rc;
+}

@@ -230,17 +230,8 @@ static float lio_ord2f(unsigned u)
 }
 
 // ------------------------------------------------------------------ set_map
-extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, size_t stride)
+static int lio_map_reserve(lio_s2m_handle* h, size_t n)
 {
-    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
-    if (n > 0 && !pts) return lio_fail(LIO_ERR_ARG, "null map pointer");
-    if (stride < 12 || (stride & 3)) return lio_fail(LIO_ERR_ARG, "stride_bytes must be >= 12 and a multiple of 4");
-    if (n >= (1ull << 25)) return lio_fail(LIO_ERR_CAPACITY, "map too large ((2k+1)^2 x n records must fit a 31-bit offset)");
-    HIPCHK(hipSetDevice(h->cfg.device_id));
-    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
-    auto t0 = std::chrono::steady_clock::now();
-    h->has_map = false;
-    h->n_map = n;
     const size_t nn = n ? n : 1;
     HIPCHK(lio_grow(&h->d_mx, &h->cap_mxyz[0], nn));
     HIPCHK(lio_grow(&h->d_my, &h->cap_mxyz[1], nn));
@@ -248,12 +239,13 @@ extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, siz
     HIPCHK(lio_grow(&h->d_map4, &h->cap_map4, nn));
     HIPCHK(lio_grow(&h->d_sorted, &h->cap_sorted, nn));
     HIPCHK(lio_grow(&h->d_cell_of, &h->cap_cell_of, nn));
-    HIPCHK(lio_grow(&h->d_stage, &h->cap_stage, nn * stride));
-    if (n) {
-        HIPCHK(hipMemcpyAsync(h->d_stage, pts, n * stride, hipMemcpyHostToDevice, h->stream));
-        lio_launch_aos_to_soa(h->d_stage, stride, (int)n, h->d_mx, h->d_my, h->d_mz, h->d_map4, h->stream);
-    }
-    // bounding box on the device
+    return LIO_OK;
+}
+
+// common tail: d_mx/d_my/d_mz/d_map4 hold the n map points -> bounding box, grid, neighbourhood rows
+static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock::time_point t0)
+{
+    const size_t nn = n ? n : 1;
     unsigned init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
     HIPCHK(hipMemcpyAsync(h->d_bbox, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
     if (n) lio_launch_map_bbox(h->d_mx, h->d_my, h->d_mz, (int)n, h->d_bbox, h->stream);
@@ -310,8 +302,45 @@ extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, siz
     h->prof.map_upload_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
     h->prof.n_map = (int64_t)n;
     h->prof.n_cells = g.n_cells;
+    h->n_map = n;
     h->has_map = true;
     return LIO_OK;
+}
+
+extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, size_t stride)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    if (n > 0 && !pts) return lio_fail(LIO_ERR_ARG, "null map pointer");
+    if (stride < 12 || (stride & 3)) return lio_fail(LIO_ERR_ARG, "stride_bytes must be >= 12 and a multiple of 4");
+    if (n >= (1ull << 25)) return lio_fail(LIO_ERR_CAPACITY, "map too large ((2k+1)^2 x n records must fit a 31-bit offset)");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
+    auto t0 = std::chrono::steady_clock::now();
+    h->has_map = false;
+    int rc = lio_map_reserve(h, n);
+    if (rc != LIO_OK) return rc;
+    HIPCHK(lio_grow(&h->d_stage, &h->cap_stage, (n ? n : 1) * stride));
+    if (n) {
+        HIPCHK(hipMemcpyAsync(h->d_stage, pts, n * stride, hipMemcpyHostToDevice, h->stream));
+        lio_launch_aos_to_soa(h->d_stage, stride, (int)n, h->d_mx, h->d_my, h->d_mz, h->d_map4, h->stream);
+    }
+    return lio_map_finish(h, n, t0);
+}
+
+// Device-resident form used by lio_assemble_map: d_xyzi = float4 (x,y,z,intensity)[n] on h's device.
+int lio_s2m_set_map_device_xyzi(lio_s2m_handle* h, const float4* d_xyzi, size_t n)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    if (n >= (1ull << 25)) return lio_fail(LIO_ERR_CAPACITY, "map too large ((2k+1)^2 x n records must fit a 31-bit offset)");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();
+    auto t0 = std::chrono::steady_clock::now();
+    h->has_map = false;
+    int rc = lio_map_reserve(h, n);
+    if (rc != LIO_OK) return rc;
+    HIPCHK(hipDeviceSynchronize());        // the producer ran on another stream
+    lio_launch_xyzi4_to_soa(d_xyzi, (int)n, h->d_mx, h->d_my, h->d_mz, h->d_map4, h->stream);
+    return lio_map_finish(h, n, t0);
 }
 
 extern "C" int lio_s2m_set_global_grid(lio_s2m_handle* h, const float origin[3], const int32_t dims[3])

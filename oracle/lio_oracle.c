@@ -1058,3 +1058,92 @@ void lo_calculate_smoothness(const float *r, size_t n, float *curvature,
         if (label) label[i] = 0;                                        /* FE:96 */
     }
 }
+
+/* ------------------------------------------------------- local-map assembly */
+/* transformPointCloud, MO:849-868: pose = [roll,pitch,yaw,x,y,z] (PointTypePose
+ * fields), xyzi packed [n][4]. */
+void lo_transform_point_cloud(const float *in_xyzi, size_t n, const float pose[6], float *out_xyzi, int trig_mode)
+{
+    float T[12];
+    lo_get_transformation(pose[3], pose[4], pose[5], pose[0], pose[1], pose[2], T, trig_mode);  /* MO:856 */
+    for (size_t i = 0; i < n; ++i) {                                    /* MO:858-866 */
+        const float *p = in_xyzi + 4 * i;
+        float *o = out_xyzi + 4 * i;
+        o[0] = T[0] * p[0] + T[1] * p[1] + T[2]  * p[2] + T[3];
+        o[1] = T[4] * p[0] + T[5] * p[1] + T[6]  * p[2] + T[7];
+        o[2] = T[8] * p[0] + T[9] * p[1] + T[10] * p[2] + T[11];
+        o[3] = p[3];
+    }
+}
+
+/* pcl::VoxelGrid<PointXYZI>::applyFilter (PCL 1.10, all fields, no filter
+ * field, min_points_per_voxel 0) as used by downSizeFilterSurf (MO:1605-1611)
+ * and downSizeFilterSurroundingKeyFrames (MO:1581-1583).  Voxel index =
+ * x-fastest linear index over the cloud's own bounding box; output in
+ * ascending voxel index; centroid = fp32 running sums / count.  PCL sorts the
+ * (voxel, point) pairs with std::sort, whose order among equal voxels is
+ * unspecified; this restatement sums a voxel's points in ascending input order.
+ * Returns 0, or 1 when PCL would pass the cloud through unfiltered (voxel
+ * index overflow, "Leaf size is too small"). */
+typedef struct { uint32_t idx; uint32_t pt; } lo_vox_pair;
+static int lo_vox_cmp(const void *a, const void *b)
+{
+    const lo_vox_pair *x = (const lo_vox_pair *)a, *y = (const lo_vox_pair *)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return x->pt < y->pt ? -1 : (x->pt > y->pt ? 1 : 0);
+}
+
+int lo_voxel_grid(const float *in_xyzi, size_t n, float leaf, float *out_xyzi, size_t *n_out)
+{
+    *n_out = 0;
+    if (n == 0) return 0;
+    const float inv = 1.0f / leaf;                                      /* inverse_leaf_size_ */
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (size_t i = 0; i < n; ++i)                                      /* getMinMax3D */
+        for (int a = 0; a < 3; ++a) {
+            float v = in_xyzi[4 * i + a];
+            if (v < mn[a]) mn[a] = v;
+            if (v > mx[a]) mx[a] = v;
+        }
+    int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1,
+            dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)INT32_MAX) {                            /* passes the input through */
+        memcpy(out_xyzi, in_xyzi, sizeof(float) * 4 * n);
+        *n_out = n;
+        return 1;
+    }
+    int min_b[3], div_b[3];
+    for (int a = 0; a < 3; ++a) {
+        min_b[a] = (int)floorf(mn[a] * inv);
+        div_b[a] = (int)floorf(mx[a] * inv) - min_b[a] + 1;
+    }
+    const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];
+    lo_vox_pair *pairs = (lo_vox_pair *)malloc(sizeof(lo_vox_pair) * n);
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = in_xyzi + 4 * i;
+        int i0 = (int)(floorf(p[0] * inv) - (float)min_b[0]);
+        int i1 = (int)(floorf(p[1] * inv) - (float)min_b[1]);
+        int i2 = (int)(floorf(p[2] * inv) - (float)min_b[2]);
+        pairs[i].idx = (uint32_t)(i0 + i1 * mul1 + i2 * mul2);
+        pairs[i].pt = (uint32_t)i;
+    }
+    qsort(pairs, n, sizeof(lo_vox_pair), lo_vox_cmp);
+    size_t o = 0;
+    for (size_t b = 0; b < n;) {
+        size_t e = b;
+        float s[4] = { 0, 0, 0, 0 };
+        while (e < n && pairs[e].idx == pairs[b].idx) {
+            const float *p = in_xyzi + 4 * (size_t)pairs[e].pt;
+            s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3];     /* AccumulatorXYZ / Intensity */
+            ++e;
+        }
+        const float cnt = (float)(e - b);
+        out_xyzi[4 * o + 0] = s[0] / cnt; out_xyzi[4 * o + 1] = s[1] / cnt;
+        out_xyzi[4 * o + 2] = s[2] / cnt; out_xyzi[4 * o + 3] = s[3] / cnt;
+        ++o;
+        b = e;
+    }
+    free(pairs);
+    *n_out = o;
+    return 0;
+}

@@ -190,6 +190,12 @@ size_t lo_project_point_cloud(const lo_deskew_config *cfg,
 void lo_calculate_smoothness(const float *range, size_t n, float *curvature,
                              int32_t *neighbor_picked, int32_t *label);
 
+/* ---- local-map assembly ---- */
+/* transformPointCloud MO:849-868 on packed xyzi[n][4]; pose = [roll,pitch,yaw,x,y,z] */
+void lo_transform_point_cloud(const float *in_xyzi, size_t n, const float pose[6], float *out_xyzi, int trig_mode);
+/* pcl::VoxelGrid centroid filter (MO:1605-1611, MO:1581-1583); out has room for n points */
+int  lo_voxel_grid(const float *in_xyzi, size_t n, float leaf, float *out_xyzi, size_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

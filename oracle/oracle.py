@@ -102,6 +102,8 @@ class Oracle:
                                              _f32p, C.c_size_t, C.c_double, _f64p, _f64p, _f64p, _f64p,
                                              C.c_int, _f32p, C.c_void_p]
         L.lo_calculate_smoothness.argtypes = [_f32p, C.c_size_t, _f32p, C.c_void_p, C.c_void_p]
+        L.lo_transform_point_cloud.argtypes = [_f32p, C.c_size_t, _f32p, _f32p, C.c_int]
+        L.lo_voxel_grid.argtypes = [_f32p, C.c_size_t, C.c_float, _f32p, C.POINTER(C.c_size_t)]
 
     # ---- helpers -----------------------------------------------------------
     def default_config(self, **kw):
@@ -245,3 +247,17 @@ class Oracle:
         label = np.full(len(rng), -1, np.int32)
         self.lib.lo_calculate_smoothness(rng, len(rng), curv, picked.ctypes.data, label.ctypes.data)
         return curv, picked, label
+
+    def transform_point_cloud(self, xyzi, pose, trig_mode=0):
+        xyzi = np.ascontiguousarray(xyzi, np.float32)
+        out = np.zeros_like(xyzi)
+        self.lib.lo_transform_point_cloud(xyzi.reshape(-1), len(xyzi), np.ascontiguousarray(pose, np.float32),
+                                          out.reshape(-1), trig_mode)
+        return out
+
+    def voxel_grid(self, xyzi, leaf):
+        xyzi = np.ascontiguousarray(xyzi, np.float32)
+        out = np.zeros_like(xyzi)
+        n_out = C.c_size_t()
+        rc = self.lib.lo_voxel_grid(xyzi.reshape(-1), len(xyzi), leaf, out.reshape(-1), C.byref(n_out))
+        return out[:n_out.value].copy(), rc
