@@ -143,6 +143,8 @@ def main():
     # ---------------------------------------------------------------- data
     B = args.batch * world
     t0 = time.time()
+    keyframes = []          # (cloud in lidar frame, pose) of every map keyframe, when generated here
+
     def generate():
         if args.case_cache and os.path.exists(args.case_cache):
             z = np.load(args.case_cache)
@@ -153,6 +155,7 @@ def main():
         case = synth.make_case(args.sensor, n_keyframes=args.keyframes, seed=synth.BASE_SEED, n_queries=B,
                                device=f"cuda:{local_rank}",
                                progress=lambda k, n: log(f"map keyframe {k}/{n}"))
+        keyframes.extend(case["keyframes"])
         sc = [q["scan"] for q in case["queries"]]
         p0 = np.stack([q["pose_init"] for q in case["queries"]]).astype(np.float32)
         pt = np.stack([q["pose_true"] for q in case["queries"]]).astype(np.float32)
@@ -288,6 +291,17 @@ def main():
             out["pose_rmse_vs_cpu"] = {"trans_m": rt, "rot_rad": rr, "scans": k,
                                        "bit_identical": int(sum(np.array_equal(a, b) for a, b in zip(poses[:k], cpu_poses))),
                                        "iters_equal": bool(list(iters[:k]) == list(cpu_iters))}
+        if keyframes and world == 1:
+            # feeder: extractCloud MO:1556-1588 on the GPU, host clouds in, map resident out
+            kc = [np.concatenate([c, np.zeros((len(c), 1), np.float32)], 1) for c, _ in keyframes]
+            kp = np.stack([p for _, p in keyframes])
+            asm = pkg.ScanToMap(device_id=local_rank)
+            pkg.assemble_map(kc, kp, 0.5, s2m=asm, want_output=False)
+            t0 = time.perf_counter()
+            _, n_asm, _ = pkg.assemble_map(kc, kp, 0.5, s2m=asm, want_output=False)
+            out["map_assembly"] = {"ms_incl_h2d_and_grid_build": 1e3 * (time.perf_counter() - t0),
+                                   "keyframes": len(kc), "points_in": int(sum(len(c) for c in kc)), "points_out": int(n_asm)}
+            asm.close()
         if args.latency and world == 1:
             lat = pkg.ScanToMap(device_id=local_rank)
             lat.set_map(map_xyz)

@@ -228,7 +228,7 @@ def keyframe_poses(n_keyframes, spacing=1.0, seed=BASE_SEED, lawnmower=False):
 
 
 def build_map(boxes, kf_poses, sensor="vlp16", seed=BASE_SEED, scan_leaf=0.4, map_leaf=0.5,
-              pose_noise=(0.01, math.radians(0.05)), device=None, progress=None):
+              pose_noise=(0.01, math.radians(0.05)), device=None, progress=None, keep=None):
     """Keyframe scans at true poses -> voxel 0.4 -> to world with noisy poses ->
     union -> voxel 0.5 (extractCloud MO:1556-1588).  Returns float32 [N_m,3]."""
     rng = np.random.Generator(np.random.MT19937(seed + 13))
@@ -240,6 +240,8 @@ def build_map(boxes, kf_poses, sensor="vlp16", seed=BASE_SEED, scan_leaf=0.4, ma
         noisy[3:6] += rng.normal(0, pose_noise[0], 3)
         noisy[0:3] += rng.normal(0, pose_noise[1], 3)
         clouds.append(transform_points(ds, noisy))
+        if keep is not None:        # keyframe clouds in the lidar frame + the poses they are placed with
+            keep.append((ds, noisy.astype(np.float32)))
         if progress and (k % 20 == 0):
             progress(k, len(kf_poses))
     return voxel_downsample(np.concatenate(clouds, 0), map_leaf)
@@ -265,7 +267,8 @@ def make_case(sensor="vlp16", n_keyframes=10, seed=BASE_SEED, kind="street", n_q
     length = max(60.0, float(n_keyframes) + 20.0) if not lawnmower else 80.0
     boxes = make_scene(seed, length=length, kind=kind)
     kfs = keyframe_poses(n_keyframes, seed=seed, lawnmower=lawnmower)
-    map_xyz = build_map(boxes, kfs, sensor, seed=seed, device=device, progress=progress)
+    kept = []
+    map_xyz = build_map(boxes, kfs, sensor, seed=seed, device=device, progress=progress, keep=kept)
     rng = np.random.Generator(np.random.MT19937(seed + 29))
     queries = []
     for q in range(n_queries):
@@ -276,4 +279,4 @@ def make_case(sensor="vlp16", n_keyframes=10, seed=BASE_SEED, kind="street", n_q
         tp[4] += 0.5 * math.sin(tp[2])
         scan, init = make_query(boxes, tp, sensor, seed=seed + 5000 + q, device=device)
         queries.append({"scan": scan, "pose_true": tp.astype(np.float32), "pose_init": init})
-    return {"map": map_xyz, "queries": queries, "boxes": boxes, "kf_poses": kfs}
+    return {"map": map_xyz, "queries": queries, "boxes": boxes, "kf_poses": kfs, "keyframes": kept}
