@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--sort", type=int, default=1)
     ap.add_argument("--celldiv", type=int, default=2)
     ap.add_argument("--xcd", type=int, default=1)
+    ap.add_argument("--tile", type=float, default=0.0)
     args = ap.parse_args()
 
     import torch
@@ -196,7 +197,7 @@ def main():
 
     # -------------------------------------------------------------- engine
     s2m = pkg.ScanToMap(device_id=local_rank, profile=1, lookahead=0, kernel_variant=args.variant,
-                        use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd)
+                        use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile)
     if world > 1:
         runner = multi.ShardedRunner(s2m, map_xyz, rank, world, dist, torch)
     else:

@@ -74,6 +74,7 @@ typedef struct lio_s2m_config {
     int32_t cell_div;        /* k: cells per search radius (1..3, default 2); the candidate
                                 scan visits (2k+1)^3 cells, map rows are replicated (2k+1)^2 x */
     int32_t xcd_remap;       /* 1 (default) = XCD-aware workgroup order (L2 locality only)  */
+    float   tile_size;       /* edge of the upload-time sort tiles in metres (0 = 4 m)      */
 } lio_s2m_config;
 
 /* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in

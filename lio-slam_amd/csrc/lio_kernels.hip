@@ -17,6 +17,8 @@
 // fp32 spacing there is > 1e7 m, they cannot be a neighbour within 1 m of anything,
 // and keeping them out keeps every squared distance finite.
 #define LIO_MAX_COORD 1.0e15f
+#define LIO_IDX_BITS 29
+#define LIO_IDX_MASK 0x1fffffff
 
 // ------------------------------------------------------------------ helpers
 LIO_DEV int lio_cell_coord(float v, float origin, float inv_cell, int n)
@@ -219,6 +221,39 @@ __global__ void k_map_nbr_count(LioGrid g, const int* __restrict__ cell_of, int 
         }
 }
 
+// Record layout of nbr_pts: records are stored in PAIRS, transposed, so that one 16-byte load
+// yields two candidates' x (and y), the next one their z (and index):
+//   float4[2p]   = (x_2p, x_2p+1, y_2p, y_2p+1)     float4[2p+1] = (z_2p, z_2p+1, w_2p, w_2p+1)
+// which is exactly the operand shape of v_pk_add_f32 / v_pk_mul_f32 (two candidates per VALU op).
+LIO_DEV void lio_nbr_store(float* __restrict__ base, int pos, float x, float y, float z, float w)
+{
+    float* p = base + (size_t)(pos >> 1) * 8 + (pos & 1);
+    p[0] = x; p[2] = y; p[4] = z; p[6] = w;
+}
+
+// Every (y,z) row list is padded to a multiple of four records (the pad goes to its last cell and
+// stays filled with dummies), so row lists start 4-aligned and an aligned group of four never
+// straddles two row lists -- neighbouring rows hold copies of the same map points, and a candidate
+// seen twice would corrupt the top-5.
+__global__ void k_map_nbr_pad_rows(LioGrid g, int* __restrict__ nbr_count)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= g.ny * g.nz) return;
+    int s = 0;
+    for (int x = 0; x < g.nx; ++x) s += nbr_count[row * g.nx + x];
+    nbr_count[row * g.nx + g.nx - 1] += (4 - (s & 3)) & 3;
+}
+
+__global__ void k_map_nbr_fill(float4* __restrict__ nbr_pts, int n_rec4)
+{
+    // unused slots (array tail, never-written padding) hold far-away dummies with a huge index:
+    // finite squared distance, never among the five nearest
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec4) return;
+    nbr_pts[i] = (i & 1) ? make_float4(LIO_MAX_COORD, LIO_MAX_COORD, __int_as_float(LIO_IDX_MASK), __int_as_float(LIO_IDX_MASK))
+                         : make_float4(LIO_MAX_COORD, LIO_MAX_COORD, LIO_MAX_COORD, LIO_MAX_COORD);
+}
+
 __global__ void k_map_nbr_scatter(LioGrid g, const float* __restrict__ x_, const float* __restrict__ y_,
                                   const float* __restrict__ z_, int n, const int* __restrict__ cell_of,
                                   const int* __restrict__ nbr_start, int* __restrict__ nbr_fill,
@@ -228,14 +263,15 @@ __global__ void k_map_nbr_scatter(LioGrid g, const float* __restrict__ x_, const
     if (i >= n) return;
     const int c = cell_of[i];
     if (c < 0) return;
-    const float4 rec = make_float4(x_[i], y_[i], z_[i], __int_as_float(i));
+    const float px = x_[i], py = y_[i], pz = z_[i], pw = __int_as_float(i);
     const int x = c % g.nx, yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
     for (int dz = -g.k; dz <= g.k; ++dz)
         for (int dy = -g.k; dy <= g.k; ++dy) {
             const int yy = y + dy, zz = z + dz;
             if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
                 const int key = (zz * g.ny + yy) * g.nx + x;
-                nbr_pts[nbr_start[key] + atomicAdd(&nbr_fill[key], 1)] = rec;
+                lio_nbr_store(reinterpret_cast<float*>(nbr_pts), nbr_start[key] + atomicAdd(&nbr_fill[key], 1),
+                              px, py, pz, pw);
             }
         }
 }
@@ -324,9 +360,6 @@ __global__ void k_scan_gather_sorted(const unsigned char* __restrict__ stage, si
 // (d2, index) order of the exact k-NN (pcl::KdTreeFLANN::nearestKSearch
 // MO:1631: ascending squared distance; ties by the smaller map index).  The
 // sorted insertion is then a branch-free chain of 9 v_min_f64 / v_max_f64.
-#define LIO_IDX_BITS 29
-#define LIO_IDX_MASK 0x1fffffff
-
 LIO_DEV double lio_dmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 LIO_DEV double lio_dmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
@@ -480,18 +513,23 @@ __global__ void k_s2m_init_state(LioScanState* __restrict__ st, int n_scans,
 }
 
 // ---- candidate scan, global-memory form -----------------------------------
-// One contiguous run of the replicated neighbourhood row (see k_map_nbr_*),
-// walked four 16-byte records per step with the next four already in flight;
-// full groups run unpredicated, the last partial group is masked.  Clamping
-// cy/cz into the grid selects a superset of the neighbourhood, which keeps the
-// search exact.
-LIO_DEV void lio_knn_group(const float4 (&m)[4], float qx, float qy, float qz, LioTop5& top)
+// One contiguous run of the replicated neighbourhood row (see k_map_nbr_*), walked in ALIGNED
+// groups of four records (64 B) with the next group already in flight.  Aligning the group
+// boundaries may pull in up to three records before and after the run: they are other map points
+// of the SAME row list (row lists are 4-aligned and padded with far-away dummies, see
+// k_map_nbr_pad_rows), i.e. a duplicate-free superset of the neighbourhood, which keeps the
+// search exact and needs no predication.  Two candidates are
+// evaluated per VALU op (v_pk_add_f32 / v_pk_mul_f32 on the pair-transposed records).
+typedef float lio_f2 __attribute__((ext_vector_type(2)));
+
+LIO_DEV void lio_knn_pair(const float4& a, const float4& b, lio_f2 qx, lio_f2 qy, lio_f2 qz, LioTop5& top)
 {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const float d2 = lio_sqdist(m[u].x, m[u].y, m[u].z, qx, qy, qz);
-        lio_top5_insert(top, lio_make_key(d2, __float_as_int(m[u].w)));
-    }
+    const lio_f2 X = { a.x, a.y }, Y = { a.z, a.w }, Z = { b.x, b.y };
+    const lio_f2 dx = X - qx, dy = Y - qy, dz = Z - qz;
+    // FLANN L2_Simple per candidate: ((dx*dx) + dy*dy) + dz*dz
+    const lio_f2 d2 = (dx * dx + dy * dy) + dz * dz;
+    lio_top5_insert(top, lio_make_key(d2.x, __float_as_int(b.z)));
+    lio_top5_insert(top, lio_make_key(d2.y, __float_as_int(b.w)));
 }
 
 LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
@@ -500,36 +538,21 @@ LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, 
     const int x0 = max(cx - g.k, 0), x1 = min(cx + g.k, g.nx - 1);
     if (x0 > x1) return;
     const int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nx;
-    const unsigned beg = (unsigned)P.nbr_start[row + x0];
+    const unsigned beg = (unsigned)P.nbr_start[row + x0] & ~3u;
     const unsigned end = (unsigned)P.nbr_start[row + x1 + 1];
     if (beg >= end) return;
-    const unsigned full = beg + ((end - beg) & ~3u);       // end of the last full group
-    const float4* p = P.nbr_pts + beg;
-    const float4* const pl = P.nbr_pts + (end - 1);        // clamp target for run-ahead loads
-    float4 cur[4], nxt[4];
-    if (beg < full) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) cur[u] = p[u];
-        for (unsigned j = beg + 4; j < full; j += 4) {
-            p += 4;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) nxt[u] = p[u];
-            lio_knn_group(cur, qx, qy, qz, top);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
-        }
-        lio_knn_group(cur, qx, qy, qz, top);
+    const lio_f2 QX = { qx, qx }, QY = { qy, qy }, QZ = { qz, qz };
+    const float4* p = P.nbr_pts + beg;                     // float4 index == record index (2 float4 per pair)
+    float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+    for (unsigned j = beg + 4; j < end; j += 4) {
+        p += 4;
+        const float4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3];
+        lio_knn_pair(c0, c1, QX, QY, QZ, top);
+        lio_knn_pair(c2, c3, QX, QY, QZ, top);
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     }
-    if (full < end) {                                      // 1..3 leftover records
-        const float4* t = P.nbr_pts + full;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const float4 m = *((t + u < pl) ? t + u : pl);
-            const float d2 = lio_sqdist(m.x, m.y, m.z, qx, qy, qz);
-            const double key = lio_make_key(d2, __float_as_int(m.w));
-            lio_top5_insert(top, (full + u < end) ? key : (double)INFINITY);
-        }
-    }
+    lio_knn_pair(c0, c1, QX, QY, QZ, top);
+    lio_knn_pair(c2, c3, QX, QY, QZ, top);
 }
 
 // ---- candidate scan, LDS form ---------------------------------------------
@@ -903,8 +926,13 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
     // replicated neighbourhood rows (9x): used by the default candidate scan
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
     hipLaunchKernelGGL(k_map_nbr_count, dim3(nb), dim3(256), 0, s, g, cell_of, n, cell_count);
+    hipLaunchKernelGGL(k_map_nbr_pad_rows, dim3((g.ny * g.nz + 255) / 256), dim3(256), 0, s, g, cell_count);
     lio_launch_exclusive_scan(cell_count, g.n_cells, tile_sums, nbr_start, s);
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
+    {
+        const int n_rec4 = n * (2 * g.k + 1) * (2 * g.k + 1) + 4 * g.ny * g.nz + 8;   // + row and tail padding
+        hipLaunchKernelGGL(k_map_nbr_fill, dim3((n_rec4 + 255) / 256), dim3(256), 0, s, nbr_pts, n_rec4);
+    }
     hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, nbr_start, cell_count, nbr_pts);
 }
 

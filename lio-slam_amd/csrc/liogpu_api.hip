@@ -139,6 +139,7 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->use_lds = 0;
     c->cell_div = 2;
     c->xcd_remap = 1;
+    c->tile_size = 0.0f;
     c->sort_scan = 1;
 }
 
@@ -282,7 +283,7 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
     HIPCHK(lio_grow(&h->d_cell_count, &h->cap_cell_count, (size_t)g.n_cells));
     HIPCHK(lio_grow(&h->d_cell_start, &h->cap_cell_start, (size_t)g.n_cells + 1));
     HIPCHK(lio_grow(&h->d_nbr_start, &h->cap_nbr_start, (size_t)g.n_cells + 1));
-    HIPCHK(lio_grow(&h->d_nbr_pts, &h->cap_nbr_pts, nn * (size_t)((2 * g.k + 1) * (2 * g.k + 1)), 1.05));
+    HIPCHK(lio_grow(&h->d_nbr_pts, &h->cap_nbr_pts, nn * (size_t)((2 * g.k + 1) * (2 * g.k + 1)) + 4 * (size_t)g.ny * g.nz + 16, 1.05));
     HIPCHK(lio_grow(&h->d_tile_sums, &h->cap_tile_sums, (size_t)lio_scan_tiles(g.n_cells) + 1));
 
     HIPCHK(hipEventRecord(h->ev_map[0], h->stream));
@@ -457,7 +458,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
                     if (fabsf(p[a]) <= 3.0e38f) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
             }
             for (int a = 0; a < 3; ++a) if (!(mn[a] <= mx[a])) { mn[a] = 0.0f; mx[a] = 0.0f; }
-            float tile = 4.0f;
+            float tile = h->cfg.tile_size > 0.0f ? h->cfg.tile_size : 4.0f;
             LioScanTiles t;
             for (;;) {
                 t.inv_tile = 1.0f / tile;
