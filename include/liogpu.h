@@ -229,6 +229,18 @@ int  lio_assemble_map(lio_s2m_handle *h, int32_t device_id, int32_t n_keyframes,
                       const size_t *n_pts, size_t stride_bytes, const float *poses, float leaf,
                       void *out, size_t out_stride_bytes, size_t *n_out);
 
+/* Device-resident keyframe store = surfCloudKeyFrames (MO:128): every keyframe cloud is
+ * uploaded once when it is saved (MO:2138-2142); lio_assemble_map_resident then builds the local
+ * map of a scan from keyframe ids + their current poses (cloudKeyPoses6D) without touching the
+ * host clouds again.  ids index the store in insertion order. */
+typedef struct lio_kf_store lio_kf_store;
+int  lio_kf_store_create(int32_t device_id, lio_kf_store **out);
+void lio_kf_store_destroy(lio_kf_store *s);
+int  lio_kf_store_add(lio_kf_store *s, const void *cloud, size_t n, size_t stride_bytes, int32_t *id_out);
+int  lio_kf_store_count(const lio_kf_store *s);
+int  lio_assemble_map_resident(lio_s2m_handle *h, lio_kf_store *s, int32_t n_selected, const int32_t *ids,
+                               const float *poses, float leaf, void *out, size_t out_stride_bytes, size_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,7 +89,8 @@ EXPORTS = [
     "lio_s2m_set_global_grid", "lio_s2m_set_shard", "lio_s2m_batch_begin",
     "lio_s2m_batch_iter_partial", "lio_s2m_batch_iter_apply", "lio_s2m_batch_n_active",
     "lio_transform_update", "lio_deskew_default_config", "lio_imu_deskew_info", "lio_deskew",
-    "lio_curvature", "lio_s2m_debug_stamps", "lio_s2m_batch_poll_active", "lio_voxel_grid", "lio_assemble_map",
+    "lio_curvature", "lio_s2m_debug_stamps", "lio_s2m_batch_poll_active", "lio_voxel_grid", "lio_assemble_map", "lio_kf_store_create", "lio_kf_store_destroy", "lio_kf_store_add",
+    "lio_kf_store_count", "lio_assemble_map_resident",
 ]
 
 
@@ -140,6 +141,12 @@ def load_library():
     L.lio_curvature.argtypes = [i32, vp, sz, vp, vp, vp]
     L.lio_s2m_debug_stamps.argtypes = [vp, vp, sz]
     L.lio_voxel_grid.argtypes = [i32, vp, sz, sz, f32, vp, sz, C.POINTER(sz)]
+    L.lio_kf_store_create.argtypes = [i32, C.POINTER(vp)]
+    L.lio_kf_store_destroy.argtypes = [vp]
+    L.lio_kf_store_destroy.restype = None
+    L.lio_kf_store_add.argtypes = [vp, vp, sz, sz, C.POINTER(i32)]
+    L.lio_kf_store_count.argtypes = [vp]
+    L.lio_assemble_map_resident.argtypes = [vp, vp, i32, C.POINTER(i32), C.POINTER(f32), f32, vp, sz, C.POINTER(sz)]
     L.lio_assemble_map.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(f32), f32, vp, sz,
                                    C.POINTER(sz)]
     _LIB = L
@@ -398,3 +405,42 @@ def assemble_map(clouds_xyzi, poses, leaf, s2m=None, device_id=0, want_output=Tr
                                                 _f32p(p), leaf, out.ctypes.data if want_output else None, 32,
                                                 C.byref(n_out)), "lio_assemble_map")
     return (_from_records(out, n_out.value) if want_output else None), n_out.value, rc
+
+
+class KeyframeStore:
+    """surfCloudKeyFrames (MO:128) kept in HBM."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        _check(self.lib.lio_kf_store_create(device_id, C.byref(self.h)), "lio_kf_store_create")
+
+    def add(self, cloud_xyzi):                      # surfCloudKeyFrames.push_back, MO:2141
+        rec = _as_xyzi_records(cloud_xyzi)
+        kid = C.c_int32()
+        _check(self.lib.lio_kf_store_add(self.h, rec.ctypes.data, len(rec), 32, C.byref(kid)), "lio_kf_store_add")
+        return kid.value
+
+    def __len__(self):
+        return self.lib.lio_kf_store_count(self.h)
+
+    def assemble(self, ids, poses, leaf, s2m=None, want_output=True, max_out=None):   # extractCloud, MO:1556-1588
+        ids_a = np.ascontiguousarray(ids, np.int32)
+        p = np.ascontiguousarray(poses, np.float32).reshape(len(ids_a), 6)
+        out = np.zeros((max(max_out or 1, 1), 8), np.float32) if want_output else None
+        n_out = C.c_size_t()
+        rc = _check(self.lib.lio_assemble_map_resident(
+            s2m.h if s2m is not None else None, self.h, len(ids_a), ids_a.ctypes.data_as(C.POINTER(C.c_int32)), _f32p(p),
+            leaf, out.ctypes.data if want_output else None, 32, C.byref(n_out)), "lio_assemble_map_resident")
+        return (_from_records(out, n_out.value) if want_output else None), n_out.value, rc
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.lio_kf_store_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -22,9 +22,11 @@ int lio_s2m_set_map_device_xyzi(lio_s2m_handle* h, const float4* d_xyzi, size_t 
         if (_e != hipSuccess) return lio_fail_ext(LIO_ERR_HIP, #expr, _e);        \
     } while (0)
 
-struct LioKfDesc {       // one keyframe cloud inside the concatenated staging buffer
-    int first;           // first point in the concatenation
+struct LioKfDesc {       // one selected keyframe
+    int src;             // first point of the keyframe in the resident store
+    int first;           // first point in the concatenated world-frame cloud
     int n;
+    int pad;
     float T[12];         // pclPointToAffine3f of its pose (MO:856), filled on the device
 };
 
@@ -39,8 +41,8 @@ __global__ void k_kf_transforms(LioKfDesc* __restrict__ kf, const float* __restr
     for (int j = 0; j < 12; ++j) kf[k].T[j] = T[j];
 }
 
-// K6: AoS records (x,y,z @0,4,8; intensity @16) of every keyframe -> world-frame float4 (x,y,z,i)
-__global__ __launch_bounds__(256) void k_transform_clouds(const unsigned char* __restrict__ src, size_t stride,
+// K6: resident keyframe clouds (float4 x,y,z,intensity, lidar frame) -> world-frame float4
+__global__ __launch_bounds__(256) void k_transform_clouds(const float4* __restrict__ store,
                                                           const LioKfDesc* __restrict__ kf,
                                                           const int2* __restrict__ chunks /* (kf, first) */,
                                                           float4* __restrict__ dst)
@@ -49,12 +51,10 @@ __global__ __launch_bounds__(256) void k_transform_clouds(const unsigned char* _
     const LioKfDesc d = kf[c.x];
     const int li = c.y + (int)threadIdx.x;
     if (li >= d.n) return;
-    const int gi = d.first + li;
-    const float* p = reinterpret_cast<const float*>(src + (size_t)gi * stride);
-    const float x = p[0], y = p[1], z = p[2];
-    dst[gi] = make_float4(d.T[0] * x + d.T[1] * y + d.T[2]  * z + d.T[3],
-                          d.T[4] * x + d.T[5] * y + d.T[6]  * z + d.T[7],
-                          d.T[8] * x + d.T[9] * y + d.T[10] * z + d.T[11], p[4]);     // MO:861-864
+    const float4 p = store[d.src + li];
+    dst[d.first + li] = make_float4(d.T[0] * p.x + d.T[1] * p.y + d.T[2]  * p.z + d.T[3],
+                                    d.T[4] * p.x + d.T[5] * p.y + d.T[6]  * p.z + d.T[7],
+                                    d.T[8] * p.x + d.T[9] * p.y + d.T[10] * p.z + d.T[11], p.w);   // MO:861-864
 }
 
 __global__ void k_aos_to_xyzi4(const unsigned char* __restrict__ src, size_t stride, int n, float4* __restrict__ dst)
@@ -320,45 +320,103 @@ extern "C" int lio_voxel_grid(int32_t device_id, const void* pts, size_t n, size
     return rc;
 }
 
-extern "C" int lio_assemble_map(lio_s2m_handle* h, int32_t device_id, int32_t n_kf, const void* const* clouds,
-                                const size_t* n_pts, size_t stride, const float* poses, float leaf,
-                                void* out, size_t out_stride, size_t* n_out)
+// ------------------------------------------------------- resident keyframe store
+// surfCloudKeyFrames (MO:128): every keyframe cloud is uploaded ONCE (MO:2138-2142) and stays in
+// HBM; assembling the local map for a scan only needs the selected ids and their current poses.
+struct lio_kf_store {
+    int device_id = 0;
+    float4* d_pts = nullptr;
+    size_t cap = 0, used = 0;
+    std::vector<size_t> off, cnt;
+};
+
+extern "C" int lio_kf_store_create(int32_t device_id, lio_kf_store** out)
 {
-    if (!clouds || !n_pts || !poses || n_kf < 0) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
-    if (stride < 20 || (stride & 3) || (out && (out_stride < 20 || (out_stride & 3))) || !(leaf > 0.0f))
-        return lio_fail_ext(LIO_ERR_ARG, "strides must be >= 20 and multiples of 4, leaf > 0", hipSuccess);
+    if (!out) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
     int rc = check_device(device_id);
     if (rc != LIO_OK) return rc;
+    lio_kf_store* s = new lio_kf_store();
+    s->device_id = device_id;
+    *out = s;
+    return LIO_OK;
+}
+
+extern "C" void lio_kf_store_destroy(lio_kf_store* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device_id);
+    if (s->d_pts) (void)hipFree(s->d_pts);
+    delete s;
+}
+
+extern "C" int lio_kf_store_count(const lio_kf_store* s) { return s ? (int)s->off.size() : 0; }
+
+extern "C" int lio_kf_store_add(lio_kf_store* s, const void* cloud, size_t n, size_t stride, int32_t* id_out)
+{
+    if (!s || (n && !cloud)) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
+    if (stride < 20 || (stride & 3)) return lio_fail_ext(LIO_ERR_ARG, "stride must be >= 20 and a multiple of 4", hipSuccess);
+    int rc = check_device(s->device_id);
+    if (rc != LIO_OK) return rc;
+    if (s->used + n > 0x7fffffffull - 1024) return lio_fail_ext(LIO_ERR_CAPACITY, "keyframe store is full", hipSuccess);
+    if (s->used + n > s->cap) {                         // grow geometrically, keep the resident clouds
+        size_t ncap = (s->cap ? s->cap * 2 : (size_t)1 << 20);
+        while (ncap < s->used + n) ncap *= 2;
+        float4* np_ = nullptr;
+        HIPCHK(hipMalloc((void**)&np_, ncap * sizeof(float4)));
+        if (s->used) HIPCHK(hipMemcpy(np_, s->d_pts, s->used * sizeof(float4), hipMemcpyDeviceToDevice));
+        if (s->d_pts) HIPCHK(hipFree(s->d_pts));
+        s->d_pts = np_;
+        s->cap = ncap;
+    }
+    if (n) {
+        Buf raw;
+        HIPCHK(raw.alloc(n * stride));
+        HIPCHK(hipMemcpyAsync(raw.p, cloud, n * stride, hipMemcpyHostToDevice, nullptr));
+        hipLaunchKernelGGL(k_aos_to_xyzi4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
+                           raw.as<unsigned char>(), stride, (int)n, s->d_pts + s->used);
+        HIPCHK(hipStreamSynchronize(nullptr));
+        HIPCHK(hipGetLastError());
+    }
+    if (id_out) *id_out = (int32_t)s->off.size();
+    s->off.push_back(s->used);
+    s->cnt.push_back(n);
+    s->used += n;
+    return LIO_OK;
+}
+
+extern "C" int lio_assemble_map_resident(lio_s2m_handle* h, lio_kf_store* st, int32_t n_sel, const int32_t* ids,
+                                         const float* poses, float leaf, void* out, size_t out_stride, size_t* n_out)
+{
+    if (!st || n_sel < 0 || (n_sel && (!ids || !poses))) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
+    if ((out && (out_stride < 20 || (out_stride & 3))) || !(leaf > 0.0f))
+        return lio_fail_ext(LIO_ERR_ARG, "output stride must be >= 20 and a multiple of 4, leaf > 0", hipSuccess);
+    int rc = check_device(st->device_id);
+    if (rc != LIO_OK) return rc;
     size_t total = 0;
-    std::vector<LioKfDesc> kf((size_t)n_kf);
+    std::vector<LioKfDesc> kf((size_t)n_sel);
     std::vector<int2> chunks;
-    for (int k = 0; k < n_kf; ++k) {
-        if (n_pts[k] && !clouds[k]) return lio_fail_ext(LIO_ERR_ARG, "null keyframe cloud", hipSuccess);
-        kf[k].first = (int)total; kf[k].n = (int)n_pts[k];
-        for (size_t b = 0; b < n_pts[k]; b += 256) chunks.push_back(make_int2(k, (int)b));
-        total += n_pts[k];
+    for (int k = 0; k < n_sel; ++k) {
+        if (ids[k] < 0 || (size_t)ids[k] >= st->off.size()) return lio_fail_ext(LIO_ERR_ARG, "unknown keyframe id", hipSuccess);
+        kf[k].src = (int)st->off[ids[k]]; kf[k].first = (int)total; kf[k].n = (int)st->cnt[ids[k]]; kf[k].pad = 0;
+        for (size_t b = 0; b < st->cnt[ids[k]]; b += 256) chunks.push_back(make_int2(k, (int)b));
+        total += st->cnt[ids[k]];
     }
     if (total > 0x7fffffffull - 1024) return lio_fail_ext(LIO_ERR_CAPACITY, "too many points", hipSuccess);
     if (n_out) *n_out = 0;
     hipStream_t s = nullptr;
-    Buf raw, d_kf, d_poses, d_chunks, world, ds;
-    HIPCHK(raw.alloc(total * stride));
+    Buf d_kf, d_poses, d_chunks, world, ds;
     HIPCHK(world.alloc(total * sizeof(float4)));
-    HIPCHK(d_kf.alloc(sizeof(LioKfDesc) * (size_t)(n_kf ? n_kf : 1)));
-    HIPCHK(d_poses.alloc(sizeof(float) * 6 * (size_t)(n_kf ? n_kf : 1)));
+    HIPCHK(d_kf.alloc(sizeof(LioKfDesc) * (size_t)(n_sel ? n_sel : 1)));
+    HIPCHK(d_poses.alloc(sizeof(float) * 6 * (size_t)(n_sel ? n_sel : 1)));
     HIPCHK(d_chunks.alloc(sizeof(int2) * (chunks.size() ? chunks.size() : 1)));
-    for (int k = 0; k < n_kf; ++k)
-        if (n_pts[k])
-            HIPCHK(hipMemcpyAsync(raw.as<unsigned char>() + (size_t)kf[k].first * stride, clouds[k], n_pts[k] * stride,
-                                  hipMemcpyHostToDevice, s));
-    if (n_kf) {
-        HIPCHK(hipMemcpyAsync(d_kf.p, kf.data(), sizeof(LioKfDesc) * (size_t)n_kf, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(d_poses.p, poses, sizeof(float) * 6 * (size_t)n_kf, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_kf_transforms, dim3((n_kf + 63) / 64), dim3(64), 0, s, d_kf.as<LioKfDesc>(), d_poses.as<float>(), n_kf);
+    if (n_sel) {
+        HIPCHK(hipMemcpyAsync(d_kf.p, kf.data(), sizeof(LioKfDesc) * (size_t)n_sel, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_poses.p, poses, sizeof(float) * 6 * (size_t)n_sel, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_kf_transforms, dim3((n_sel + 63) / 64), dim3(64), 0, s, d_kf.as<LioKfDesc>(), d_poses.as<float>(), n_sel);
     }
     if (!chunks.empty()) {
         HIPCHK(hipMemcpyAsync(d_chunks.p, chunks.data(), sizeof(int2) * chunks.size(), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_transform_clouds, dim3((unsigned)chunks.size()), dim3(256), 0, s, raw.as<unsigned char>(), stride,
+        hipLaunchKernelGGL(k_transform_clouds, dim3((unsigned)chunks.size()), dim3(256), 0, s, st->d_pts,
                            d_kf.as<LioKfDesc>(), d_chunks.as<int2>(), world.as<float4>());
     }
     HIPCHK(hipStreamSynchronize(s));       // kf / chunks are stack vectors
@@ -372,5 +430,21 @@ extern "C" int lio_assemble_map(lio_s2m_handle* h, int32_t device_id, int32_t n_
     const int rc2 = copy_out(ds.as<float4>(), no, out, out_stride, s);
     if (rc2 < 0) return rc2;
     if (n_out) *n_out = (size_t)no;
+    return rc;
+}
+
+// One-shot form: host keyframe clouds in, map out (uploads into a temporary store).
+extern "C" int lio_assemble_map(lio_s2m_handle* h, int32_t device_id, int32_t n_kf, const void* const* clouds,
+                                const size_t* n_pts, size_t stride, const float* poses, float leaf,
+                                void* out, size_t out_stride, size_t* n_out)
+{
+    if (!clouds || !n_pts || !poses || n_kf < 0) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
+    lio_kf_store* st = nullptr;
+    int rc = lio_kf_store_create(device_id, &st);
+    if (rc != LIO_OK) return rc;
+    std::vector<int32_t> ids((size_t)n_kf);
+    for (int k = 0; k < n_kf && rc == LIO_OK; ++k) rc = lio_kf_store_add(st, clouds[k], n_pts[k], stride, &ids[k]);
+    if (rc == LIO_OK) rc = lio_assemble_map_resident(h, st, n_kf, ids.data(), poses, leaf, out, out_stride, n_out);
+    lio_kf_store_destroy(st);
     return rc;
 }

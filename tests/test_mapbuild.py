@@ -122,4 +122,21 @@ def test_gpu_assemble_map_matches_oracle_and_feeds_registration(pkg, oracle, syn
     # no keyframes: empty map
     out, n0, rc = pkg.assemble_map([], np.zeros((0, 6), np.float32), 0.5)
     assert n0 == 0
-    s2m.close(); ref.close()
+    # resident keyframe store (surfCloudKeyFrames kept in HBM): a subset, in another order, new poses
+    store = pkg.KeyframeStore()
+    ids = [store.add(c) for c in clouds]
+    assert ids == list(range(len(clouds))) and len(store) == len(clouds)
+    sel = [4, 1, 3]
+    poses2 = poses[sel] + np.array([0.001, -0.002, 0.01, 0.05, -0.03, 0.0], np.float32)
+    world2 = np.concatenate([oracle.transform_point_cloud(clouds[i], p) for i, p in zip(sel, poses2)])
+    map_o2, _ = oracle.voxel_grid(world2, 0.5)
+    map_g2, n2, rc = store.assemble(sel, poses2, 0.5, s2m=s2m, max_out=len(world2))
+    assert n2 == len(map_o2)
+    np.testing.assert_array_equal(map_g2.view(np.uint32), map_o2.view(np.uint32))
+    pose_c, res_c, _ = s2m.scan2MapOptimization(scan, init)          # registers against the new resident map
+    ref.set_map(map_o2[:, :3])
+    pose_d, res_d, _ = ref.scan2MapOptimization(scan, init)
+    np.testing.assert_array_equal(pose_c, pose_d)
+    with pytest.raises(pkg.LioError):
+        store.assemble([99], poses2[:1], 0.5)
+    store.close(); s2m.close(); ref.close()
