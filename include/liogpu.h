@@ -69,7 +69,8 @@ typedef struct lio_s2m_config {
                                 0 = never enqueue an empty launch, -1 = auto               */
     int32_t use_lds;         /* 1 = stage the workgroup's map region through LDS;
                                 0 (default) = stream the replicated neighbourhood rows     */
-    int32_t sort_scan;       /* 1 = re-order scans by 4 m tiles at upload (default);
+    int32_t sort_scan;       /* 1 = re-order scans by tiles at upload when the batch has >= 65536
+                                points (default), 2 = always, 0 = never;
                                 results are reported in the caller's order either way      */
     int32_t cell_div;        /* k: cells per search radius (1..3, default 2); the candidate
                                 scan visits (2k+1)^3 cells, map rows are replicated (2k+1)^2 x */

@@ -70,6 +70,9 @@ struct lio_s2m_handle {
     float *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr; size_t cap_sxyz[3] = {0, 0, 0};
     LioScanState* d_state = nullptr; size_t cap_state = 0;
     std::vector<LioScanState> h_state;
+    std::vector<LioBlockDesc> v_blocks, v_prep;      // launch descriptors (kept alive for async H2D)
+    std::vector<LioScanTiles> v_tiles;
+    bool defer_sync = false;                         // lio_s2m_register: one sync at the end of the call
     float* d_poses = nullptr; size_t cap_poses = 0;
     LioBlockDesc* d_blocks = nullptr; size_t cap_blocks = 0;
     int n_blocks = 0, ppt = 1, max_blk = 1;
@@ -400,7 +403,8 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     }
     h->ppt = ppt;
     const size_t per_blk = (size_t)LIO_BLOCK * ppt;
-    std::vector<LioBlockDesc> blocks;
+    std::vector<LioBlockDesc>& blocks = h->v_blocks;
+    blocks.clear();
     int max_blk = 1;
     const size_t old_scans = h->h_state.size();
     h->h_state.resize((size_t)n_scans);
@@ -442,10 +446,12 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
                               hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state.data(), (size_t)n_scans * sizeof(LioScanState),
                           hipMemcpyHostToDevice, h->stream));
-    std::vector<LioScanTiles> tiles;
-    std::vector<LioBlockDesc> prep;
+    std::vector<LioScanTiles>& tiles = h->v_tiles;
+    std::vector<LioBlockDesc>& prep = h->v_prep;
+    tiles.clear(); prep.clear();
     h->sorted = false;
-    if (total && h->cfg.sort_scan) {
+    // the tile sort pays for itself on batches; a lone small scan skips its eight launches
+    if (total && (h->cfg.sort_scan == 2 || (h->cfg.sort_scan == 1 && total >= 65536))) {
         // scan-local tile grids from the host-side bounding boxes
         tiles.resize((size_t)n_scans);
         long long n_keys = 0;
@@ -494,7 +500,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     if (total && !h->sorted)
         lio_launch_aos_to_soa(h->d_stage, stride, (int)total, h->d_sx, h->d_sy, h->d_sz, nullptr, h->stream);
     HIPCHK(hipMemsetAsync(h->d_arrive, 0, (size_t)n_scans * sizeof(unsigned), h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));   // `blocks` and the caller's scans are borrowed only for this call
+    if (!h->defer_sync) HIPCHK(hipStreamSynchronize(h->stream));   // the caller's scans are borrowed only for this call
     HIPCHK(hipGetLastError());
     h->poses_set = false;
     h->ran = false;
@@ -508,7 +514,7 @@ extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     HIPCHK(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_scans * 6 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!h->defer_sync) HIPCHK(hipStreamSynchronize(h->stream));
     h->poses_set = true;
     return LIO_OK;
 }
@@ -728,10 +734,14 @@ extern "C" int lio_s2m_register(lio_s2m_handle* h, const void* scan, size_t n, s
     if (!h->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
     const void* scans[1] = { scan };
     size_t np[1] = { n };
-    int rc;
-    if ((rc = lio_s2m_batch_upload(h, 1, scans, np, stride)) != LIO_OK) return rc;
-    if ((rc = lio_s2m_batch_set_poses(h, pose)) != LIO_OK) return rc;
-    if ((rc = lio_s2m_batch_run(h)) != LIO_OK) return rc;
+    // upload, poses and the GN loop are chained on the stream; the only host wait is for the results
+    // (the caller's buffers stay valid for the whole call)
+    h->defer_sync = true;
+    int rc = lio_s2m_batch_upload(h, 1, scans, np, stride);
+    if (rc == LIO_OK) rc = lio_s2m_batch_set_poses(h, pose);
+    if (rc == LIO_OK) rc = lio_s2m_batch_run(h);
+    h->defer_sync = false;
+    if (rc != LIO_OK) { (void)hipStreamSynchronize(h->stream); return rc; }
     lio_s2m_result local;
     if ((rc = lio_s2m_batch_results(h, pose, res ? res : &local)) != LIO_OK) return rc;
     return (res ? res : &local)->status;

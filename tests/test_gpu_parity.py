@@ -57,9 +57,9 @@ def test_register_matches_oracle(pkg, oracle, small_case):
 
 
 @pytest.mark.parametrize("variant", [
-    dict(use_lds=0, sort_scan=0), dict(use_lds=1, sort_scan=0), dict(use_lds=0, sort_scan=1),
-    dict(use_lds=1, sort_scan=1, kernel_variant=2), dict(use_lds=1, sort_scan=1, kernel_variant=4),
-    dict(use_lds=0, sort_scan=1, kernel_variant=4), dict(use_lds=1, sort_scan=1, cell_size=2.5),
+    dict(use_lds=0, sort_scan=0), dict(use_lds=1, sort_scan=0), dict(use_lds=0, sort_scan=2),
+    dict(use_lds=1, sort_scan=2, kernel_variant=2), dict(use_lds=1, sort_scan=2, kernel_variant=4),
+    dict(use_lds=0, sort_scan=2, kernel_variant=4), dict(use_lds=1, sort_scan=2, cell_size=2.5),
     dict(cell_div=1), dict(cell_div=2, cell_size=1.7), dict(cell_div=3, sort_scan=0),
 ])
 def test_kernel_variants_are_equivalent(pkg, oracle, small_case, variant):
