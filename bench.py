@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--celldiv", type=int, default=2)
     ap.add_argument("--xcd", type=int, default=1)
     ap.add_argument("--tile", type=float, default=0.0)
+    ap.add_argument("--lookahead", type=int, default=0)
+    ap.add_argument("--lawnmower", action="store_true", help="keyframes on a lawn-mower path inside a 50 m radius (configs[3])")
     args = ap.parse_args()
 
     import torch
@@ -154,7 +156,7 @@ def main():
             assert len(sc) == B, "case cache was generated for another batch size"
             return z["map"], sc, z["poses0"], z["poses_true"]
         case = synth.make_case(args.sensor, n_keyframes=args.keyframes, seed=synth.BASE_SEED, n_queries=B,
-                               device=f"cuda:{local_rank}",
+                               device=f"cuda:{local_rank}", lawnmower=args.lawnmower,
                                progress=lambda k, n: log(f"map keyframe {k}/{n}"))
         keyframes.extend(case["keyframes"])
         sc = [q["scan"] for q in case["queries"]]
@@ -196,7 +198,7 @@ def main():
         f"B={B} gen {time.time() - t0:.1f}s")
 
     # -------------------------------------------------------------- engine
-    s2m = pkg.ScanToMap(device_id=local_rank, profile=1, lookahead=0, kernel_variant=args.variant,
+    s2m = pkg.ScanToMap(device_id=local_rank, profile=1, lookahead=args.lookahead, kernel_variant=args.variant,
                         use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile)
     if world > 1:
         runner = multi.ShardedRunner(s2m, map_xyz, rank, world, dist, torch)

@@ -42,7 +42,7 @@ int main(int argc, char** argv)
         } else {
             std::fprintf(stderr, "Not enough features! Only %d planar features available.\n", laserCloudSurfLastDSNum);
         }
-        std::printf("iters %d converged %d degenerate %d corr %d pose %.7g %.7g %.7g %.7g %.7g %.7g\n", s2m.last.iters,
+        std::printf("iters %d converged %d degenerate %d corr %d pose %.9g %.9g %.9g %.9g %.9g %.9g\n", s2m.last.iters,
                     s2m.last.converged, (int)s2m.isDegenerate, s2m.last.n_corr_last, s2m.transformTobeMapped[0],
                     s2m.transformTobeMapped[1], s2m.transformTobeMapped[2], s2m.transformTobeMapped[3],
                     s2m.transformTobeMapped[4], s2m.transformTobeMapped[5]);
