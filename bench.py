@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--xcd", type=int, default=1)
     ap.add_argument("--tile", type=float, default=0.0)
     ap.add_argument("--lookahead", type=int, default=0)
+    ap.add_argument("--shard", choices=["map", "scan"], default="scan",
+                    help="N>1: map = slabs of the map + halo, owner-computes (north_star); scan = map replicated, workgroups of every scan dealt round-robin")
     ap.add_argument("--lawnmower", action="store_true", help="keyframes on a lawn-mower path inside a 50 m radius (configs[3])")
     args = ap.parse_args()
 
@@ -198,22 +200,26 @@ def main():
         f"B={B} gen {time.time() - t0:.1f}s")
 
     # -------------------------------------------------------------- engine
-    s2m = pkg.ScanToMap(device_id=local_rank, profile=1, lookahead=args.lookahead, kernel_variant=args.variant,
-                        use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile)
+    kcfg = dict(device_id=local_rank, profile=1, lookahead=args.lookahead, kernel_variant=args.variant,
+                use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile)
     if world > 1:
-        runner = multi.ShardedRunner(s2m, map_xyz, rank, world, dist, torch)
+        runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2, **kcfg)
+        runner.upload(scans)
+        s2m = runner.handles[0]
     else:
-        s2m.set_map(map_xyz)
         runner = None
-    s2m.batch_upload(scans)
+        s2m = pkg.ScanToMap(**kcfg)
+        s2m.set_map(map_xyz)
+        s2m.batch_upload(scans)
     prof0 = s2m.profile()
 
     def step():
-        s2m.batch_set_poses(poses0)
         if runner:
+            runner.set_poses(poses0)
             runner.run()
-        else:
-            s2m.batch_run()
+            return runner.results(with_results=False)[0]
+        s2m.batch_set_poses(poses0)
+        s2m.batch_run()
         return s2m.batch_results(with_results=False)[0]
 
     def sync_all():
@@ -228,7 +234,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         poses = step()
-    s2m.batch_sync()
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist:
@@ -237,14 +242,25 @@ def main():
         elapsed = float(t.item())
 
     # per-launch accounting from the last timed step
-    poses, results = s2m.batch_results(with_results=True)
-    prof = s2m.profile()
-    iters = np.array([r.iters for r in results])
-    n_launch = prof.n_launches
-    lms = np.array(prof.launch_ms[:n_launch], dtype=np.float64)
-    pts_per_launch = np.array([int(n_s[iters > i].sum()) for i in range(n_launch)], dtype=np.float64)
-    if runner:   # sharded: this rank touches only the points it owns; price the whole-job bytes on N GPUs
-        pts_per_launch = pts_per_launch / world
+    if runner:
+        poses, results = runner.results(with_results=True)
+        iters = np.array([r.iters for r in results])
+        lms, pts_per_launch = [], []
+        for (a, b_), hh in zip(runner.split, runner.handles):      # every sub-batch has its own launches
+            pr = hh.profile()
+            for i in range(pr.n_launches):
+                lms.append(pr.launch_ms[i])
+                # this rank handles 1/world of the points of the scans still iterating
+                pts_per_launch.append(float(n_s[a:b_][iters[a:b_] > i].sum()) / world)
+        lms, pts_per_launch = np.array(lms, dtype=np.float64), np.array(pts_per_launch, dtype=np.float64)
+        n_launch = len(lms)
+    else:
+        poses, results = s2m.batch_results(with_results=True)
+        prof = s2m.profile()
+        iters = np.array([r.iters for r in results])
+        n_launch = prof.n_launches
+        lms = np.array(prof.launch_ms[:n_launch], dtype=np.float64)
+        pts_per_launch = np.array([int(n_s[iters > i].sum()) for i in range(n_launch)], dtype=np.float64)
     live = pts_per_launch > 0
     bytes_per_launch = BYTES_PER_POINT_ITER * pts_per_launch[live].mean() if live.any() else 0.0
     ms_per_launch = float(lms[live].mean()) if live.any() else float("nan")
@@ -268,7 +284,9 @@ def main():
                         f"(BASELINE.json headline / configs[4] batched form)",
             "scans_per_step": B, "N_s_mean": float(n_s.mean()), "N_m": int(len(map_xyz)),
             "gn_iters_mean": float(iters.mean()), "gn_iters_max": int(iters.max()),
-            "parallelism": "single GPU" if world == 1 else f"map sharded x{world} + RCCL all-reduce of JtJ/Jtr per GN iteration",
+            "parallelism": "single GPU" if world == 1 else
+            (f"map sharded x{world} (slabs + halo, owner-computes)" if args.shard == "map" else
+             f"map replicated, scan workgroups dealt over {world} ranks") + " + RCCL all-reduce of JtJ/Jtr per GN iteration",
             "kernel": {"points_per_thread": int(args.variant), "lds_staging": int(args.lds),
                        "tile_sorted_scans": int(args.sort), "cell_div": int(args.celldiv)},
         },
@@ -325,7 +343,10 @@ def main():
             out["single_scan_ms_incl_h2d"] = 1e3 * (time.perf_counter() - t0) / n_lat
             lat.close()
         print(json.dumps(out), flush=True)
-    s2m.close()
+    if runner:
+        runner.close()
+    else:
+        s2m.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -159,6 +159,10 @@ int  lio_s2m_debug_stamps(lio_s2m_handle *h, long long *out, size_t cap_entries)
 int  lio_s2m_set_stream(lio_s2m_handle *h, void *hip_stream);
 int  lio_s2m_set_global_grid(lio_s2m_handle *h, const float origin[3], const int32_t dims[3]);
 int  lio_s2m_set_shard(lio_s2m_handle *h, int32_t axis, int32_t lo, int32_t hi);
+/* Alternative partition: the map is replicated, every rank processes each world-th
+ * workgroup of every scan (call before lio_s2m_batch_upload); same iter_partial / all-reduce /
+ * iter_apply protocol.  No halo, no ownership tests, perfectly balanced. */
+int  lio_s2m_set_scan_shard(lio_s2m_handle *h, int32_t rank, int32_t world);
 int  lio_s2m_batch_begin(lio_s2m_handle *h);
 int  lio_s2m_batch_iter_partial(lio_s2m_handle *h, double *d_sums /* device, n_scans x 32 */);
 int  lio_s2m_batch_iter_apply(lio_s2m_handle *h, const double *d_sums);

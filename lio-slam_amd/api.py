@@ -90,7 +90,7 @@ EXPORTS = [
     "lio_s2m_batch_iter_partial", "lio_s2m_batch_iter_apply", "lio_s2m_batch_n_active",
     "lio_transform_update", "lio_deskew_default_config", "lio_imu_deskew_info", "lio_deskew",
     "lio_curvature", "lio_s2m_debug_stamps", "lio_s2m_batch_poll_active", "lio_voxel_grid", "lio_assemble_map", "lio_kf_store_create", "lio_kf_store_destroy", "lio_kf_store_add",
-    "lio_kf_store_count", "lio_assemble_map_resident",
+    "lio_kf_store_count", "lio_assemble_map_resident", "lio_s2m_set_scan_shard",
 ]
 
 
@@ -125,6 +125,7 @@ def load_library():
     L.lio_s2m_set_stream.argtypes = [vp, vp]
     L.lio_s2m_set_global_grid.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
     L.lio_s2m_set_shard.argtypes = [vp, i32, i32, i32]
+    L.lio_s2m_set_scan_shard.argtypes = [vp, i32, i32]
     L.lio_s2m_batch_begin.argtypes = [vp]
     L.lio_s2m_batch_iter_partial.argtypes = [vp, vp]
     L.lio_s2m_batch_iter_apply.argtypes = [vp, vp]
@@ -278,6 +279,9 @@ class ScanToMap:
 
     def set_shard(self, axis, lo, hi):
         _check(self.lib.lio_s2m_set_shard(self.h, axis, lo, hi), "lio_s2m_set_shard")
+
+    def set_scan_shard(self, rank, world):
+        _check(self.lib.lio_s2m_set_scan_shard(self.h, rank, world), "lio_s2m_set_scan_shard")
 
     def batch_begin(self):
         _check(self.lib.lio_s2m_batch_begin(self.h), "lio_s2m_batch_begin")

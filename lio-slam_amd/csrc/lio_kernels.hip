@@ -596,6 +596,45 @@ __constant__ int c_pair_b[32] = { 0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5, 4,5, 5
 #define LIO_LDS_CELLS 1536     // staged run offsets (6 KiB)
 #define LIO_LDS_ROWS  256      // (y,z) rows of a region
 
+// Tail of an association workgroup, executed by its wave 0 after the partial sums were stored
+// write-through: drain, arrive on the scan's counter; the workgroup whose arrival is last adds up
+// the scan's partials in workgroup order and runs the Gauss-Newton step (or publishes the sums).
+LIO_DEV void lio_arrive_and_finish(const LioIterParams& P, const LioBlockDesc& bd, LioScanState* st, int lane,
+                                   double* s_sum, LioSolveWs* s_ws, long long* stamp)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last = 0;
+    if (lane == 0) {
+        const unsigned old = atomicAdd(&P.arrive[bd.scan], 1u);
+        last = (old == (unsigned)bd.n_blk - 1u);
+    }
+    last = __shfl(last, 0);
+    if (stamp && lane == 0) stamp[6] = (long long)__builtin_readcyclecounter();
+    if (!last) return;
+
+    // last workgroup of this scan: fixed-order sum over the scan's chunks
+    if (lane < 28) {
+        const double* base_p = P.partials + (size_t)bd.scan * P.max_blk * LIO_SUMS + lane;
+        double v = 0.0;
+        for (int b = 0; b < bd.n_blk; b += 8) {          // 8 write-through loads in flight, summed in chunk order
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                t[u] = __hip_atomic_load(base_p + (size_t)min(b + u, bd.n_blk - 1) * LIO_SUMS,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += (b + u < bd.n_blk) ? t[u] : 0.0;
+        }
+        s_sum[lane] = v;
+        if (P.sums_out) P.sums_out[(size_t)bd.scan * LIO_SUMS + lane] = v;
+    }
+    __builtin_amdgcn_wave_barrier();      // same wave: LDS ops retire in order
+    if (lane == 0) {
+        P.arrive[bd.scan] = 0;            // re-arm for the next launch
+        if (!P.sums_out) lio_gn_step(st, s_sum, P.c, s_ws, P.n_active);
+    }
+}
+
 // One thread = one scan point (x PPT points, strided by the workgroup size).
 // STAGE: the workgroup's points are spatially sorted at upload, so their
 // 27-cell neighbourhoods overlap heavily: the union region of the map is staged
@@ -676,6 +715,21 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
             bmn[0] = min(bmn[0], cx[pp]); bmx[0] = max(bmx[0], cx[pp]);
             bmn[1] = min(bmn[1], cy[pp]); bmx[1] = max(bmx[1], cy[pp]);
             bmn[2] = min(bmn[2], cz[pp]); bmx[2] = max(bmx[2], cz[pp]);
+        }
+    }
+
+    // A workgroup none of whose points is active (typically: owned by other ranks) only reports
+    // an all-zero partial sum and leaves.
+    if (P.shard.axis >= 0) {
+        bool any = false;
+#pragma unroll
+        for (int pp = 0; pp < PPT; ++pp) any = any || act[pp];
+        if (!__syncthreads_or(any ? 1 : 0)) {
+            if (wave != 0) return;
+            double* part0 = P.partials + ((size_t)bd.scan * P.max_blk + bd.blk) * LIO_SUMS;
+            if (lane < 28) __hip_atomic_store(part0 + lane, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lio_arrive_and_finish(P, bd, st, lane, s_sum, &s_ws, stamp);   // (recorded flags stay "rejected")
+            return;
         }
     }
 
@@ -842,37 +896,7 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
         // write-through (sc1) store: visible to the other XCDs without a release fence
         __hip_atomic_store(part + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int last = 0;
-    if (lane == 0) {
-        const unsigned old = atomicAdd(&P.arrive[bd.scan], 1u);
-        last = (old == (unsigned)bd.n_blk - 1u);
-    }
-    last = __shfl(last, 0);
-    LIO_STAMP(6);
-    if (!last) return;
-
-    // last workgroup of this scan: fixed-order sum over the scan's chunks
-    if (lane < 28) {
-        const double* base_p = P.partials + (size_t)bd.scan * P.max_blk * LIO_SUMS + lane;
-        double v = 0.0;
-        for (int b = 0; b < bd.n_blk; b += 8) {          // 8 write-through loads in flight, summed in chunk order
-            double t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                t[u] = __hip_atomic_load(base_p + (size_t)min(b + u, bd.n_blk - 1) * LIO_SUMS,
-                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v += (b + u < bd.n_blk) ? t[u] : 0.0;
-        }
-        s_sum[lane] = v;
-        if (P.sums_out) P.sums_out[(size_t)bd.scan * LIO_SUMS + lane] = v;
-    }
-    __builtin_amdgcn_wave_barrier();      // same wave: LDS ops retire in order
-    if (lane == 0) {
-        P.arrive[bd.scan] = 0;            // re-arm for the next launch
-        if (!P.sums_out) lio_gn_step(st, s_sum, P.c, &s_ws, P.n_active);
-    }
+    lio_arrive_and_finish(P, bd, st, lane, s_sum, &s_ws, stamp);
     LIO_STAMP(7);
 #undef LIO_STAMP
 }

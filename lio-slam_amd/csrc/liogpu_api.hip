@@ -101,6 +101,7 @@ struct lio_s2m_handle {
     float gorigin[3] = {0, 0, 0};
     int gdims[3] = {0, 0, 0};
     bool has_global = false;
+    int block_rank = 0, block_world = 1;   // scan-range sharding
 
     // profiling
     hipEvent_t ev_beg[LIO_MAX_ITERS], ev_end[LIO_MAX_ITERS], ev_chk[LIO_MAX_ITERS];
@@ -355,6 +356,14 @@ extern "C" int lio_s2m_set_global_grid(lio_s2m_handle* h, const float origin[3],
     return LIO_OK;
 }
 
+extern "C" int lio_s2m_set_scan_shard(lio_s2m_handle* h, int32_t rank, int32_t world)
+{
+    if (!h || world < 1 || rank < 0 || rank >= world) return lio_fail(LIO_ERR_ARG, "need 0 <= rank < world");
+    h->block_rank = rank;
+    h->block_world = world;
+    return LIO_OK;
+}
+
 extern "C" int lio_s2m_set_shard(lio_s2m_handle* h, int32_t axis, int32_t lo, int32_t hi)
 {
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
@@ -416,8 +425,16 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         st.offset = (int)off;
         st.done = 1;
         const int nb = (int)((n_pts[s] + per_blk - 1) / per_blk);
-        if (nb > max_blk) max_blk = nb;
-        for (int b = 0; b < nb; ++b) blocks.push_back({ s, (int)(b * per_blk), b, nb });
+        // scan-range sharding ("replicate the map, shard the scan"): this rank takes one
+        // block_world-th of the workgroups of every scan; the per-scan sums are all-reduced by the caller
+        // a contiguous range of the (tile-sorted) workgroups, rotated from scan to scan so that no rank
+        // always gets the same part of the sweep
+        const int bw = h->block_world > 1 ? h->block_world : 1, br = h->block_world > 1 ? h->block_rank : 0;
+        const int part = (br + s) % bw;
+        const int b0 = (int)((long long)nb * part / bw), b1 = (int)((long long)nb * (part + 1) / bw);
+        const int nb_local = b1 - b0;
+        if (nb_local > max_blk) max_blk = nb_local;
+        for (int b = b0; b < b1; ++b) blocks.push_back({ s, (int)(b * per_blk), b - b0, nb_local });
         if (n_pts[s])
             HIPCHK(hipMemcpyAsync(h->d_stage + off * stride, scans[s], n_pts[s] * stride,
                                   hipMemcpyHostToDevice, h->stream));

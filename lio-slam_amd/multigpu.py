@@ -89,50 +89,113 @@ def transform_f32(T, xyz):
 
 
 class ShardedRunner:
-    """GN loop over a sharded map: partial sums on this GPU -> all-reduce -> solve.
+    """Gauss-Newton loop of one rank when a job is spread over `world` GPUs.
 
-    The shard's neighbour indices refer to the shard-local order; poses, iteration
-    counts and degeneracy flags are identical on every rank because every rank
-    solves from the same all-reduced sums.
+    mode "map" : the map is cut into slabs + halo, owner-computes (north_star).
+    mode "scan": the map is replicated and every rank takes one world-th of the workgroups of
+                 every scan (SURVEY 8e alternative): no halo, no ownership tests, balanced.
+    Either way the per-scan sums (n_scans x 32 doubles) are all-reduced once per iteration and every
+    rank runs the same solve, so poses, iteration counts and degeneracy flags are identical on all
+    ranks.  The batch is processed as `groups` sub-batches in a software pipeline: while the
+    all-reduce of one sub-batch is in flight (RCCL runs on its own stream), the association kernel of
+    the next one runs, so the collective latency is hidden behind compute.
     """
 
-    def __init__(self, s2m, map_xyz, rank, world, dist, torch, deterministic=False, lookahead=1):
-        self.s2m, self.rank, self.world, self.dist, self.torch = s2m, rank, world, dist, torch
-        self.plan = plan_shards(map_xyz, world)
-        self.idx = shard_points(map_xyz, self.plan, rank)
-        s2m.set_map(np.ascontiguousarray(np.asarray(map_xyz, np.float32)[self.idx]))
-        s2m.set_global_grid([float(v) for v in self.plan["origin"]], [int(v) for v in self.plan["dims"]])
-        s2m.set_shard(self.plan["axis"], int(self.plan["bounds"][rank]), int(self.plan["bounds"][rank + 1]))
-        # kernels and the collective share torch's current stream
-        s2m.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.deterministic = deterministic
-        self.lookahead = lookahead      # iterations enqueued ahead of the all-scans-done check
-        self.sums = None
+    def __init__(self, pkg, map_xyz, rank, world, dist, torch, mode="map", groups=2, deterministic=False,
+                 lookahead=1, **cfg):
+        self.rank, self.world, self.dist, self.torch = rank, world, dist, torch
+        self.mode, self.deterministic, self.lookahead = mode, deterministic, lookahead
+        self.handles = []
+        map_xyz = np.ascontiguousarray(map_xyz, np.float32)
+        if mode == "map":
+            self.plan = plan_shards(map_xyz, world)
+            self.idx = shard_points(map_xyz, self.plan, rank)
+        else:
+            self.idx = np.arange(len(map_xyz))
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(max(1, groups)):
+            s2m = pkg.ScanToMap(**cfg)
+            if mode == "map":
+                s2m.set_map(np.ascontiguousarray(map_xyz[self.idx]))
+                s2m.set_global_grid([float(v) for v in self.plan["origin"]], [int(v) for v in self.plan["dims"]])
+                s2m.set_shard(self.plan["axis"], int(self.plan["bounds"][rank]), int(self.plan["bounds"][rank + 1]))
+            else:
+                s2m.set_map(map_xyz)
+                s2m.set_scan_shard(rank, world)
+            s2m.set_stream(stream)           # kernels and collectives are ordered through torch's current stream
+            self.handles.append(s2m)
+        self.split = []                      # (first, last) scan of every group
+        self.sums, self.gathered = [], []
+
+    def upload(self, scans):
+        n, g = len(scans), len(self.handles)
+        if n < g:
+            g = 1
+        bounds = [n * k // g for k in range(g + 1)]
+        self.split = [(bounds[k], bounds[k + 1]) for k in range(g)]
+        self.sums, self.gathered = [], []
+        for (a, b), h in zip(self.split, self.handles):
+            h.batch_upload(scans[a:b])
+            self.sums.append(self.torch.zeros((b - a, SUMS), dtype=self.torch.float64, device="cuda"))
+            self.gathered.append(self.torch.zeros((self.world * (b - a), SUMS), dtype=self.torch.float64, device="cuda")
+                                 if self.deterministic else None)
+
+    def set_poses(self, poses):
+        poses = np.ascontiguousarray(poses, np.float32)
+        for (a, b), h in zip(self.split, self.handles):
+            h.batch_set_poses(poses[a:b])
+
+    def _reduce(self, k):
+        dist = self.dist
+        if self.deterministic:
+            # bitwise reproducible across runs: gather, then sum in rank order
+            dist.all_gather_into_tensor(self.gathered[k], self.sums[k])
+            g = self.gathered[k].view(self.world, -1, SUMS)
+            self.sums[k].copy_(g[0])
+            for r in range(1, self.world):
+                self.sums[k].add_(g[r])
+            return None
+        return dist.all_reduce(self.sums[k], op=dist.ReduceOp.SUM, async_op=True)
 
     def run(self):
-        s2m, torch, dist = self.s2m, self.torch, self.dist
-        n = s2m._n_scans
-        if self.sums is None or self.sums.shape[0] != n:
-            self.sums = torch.zeros((n, SUMS), dtype=torch.float64, device="cuda")
-            self.gathered = torch.zeros((self.world * n, SUMS), dtype=torch.float64, device="cuda")
-        s2m.batch_begin()
+        hs = self.handles[:len(self.split)]
+        live = [True] * len(hs)
+        work = [None] * len(hs)
+        for k, h in enumerate(hs):                                   # prologue: iteration 0 of every group
+            h.batch_begin()
+            h.batch_iter_partial(self.sums[k].data_ptr())
+            work[k] = self._reduce(k)
         iters = 0
-        for it in range(s2m.cfg.max_iters):                      # MO:1848
-            s2m.batch_iter_partial(self.sums.data_ptr())
-            if self.deterministic:
-                # bitwise reproducible across runs: gather, then sum in rank order
-                dist.all_gather_into_tensor(self.gathered, self.sums)
-                g = self.gathered.view(self.world, n, SUMS)
-                self.sums.copy_(g[0])
-                for r in range(1, self.world):
-                    self.sums.add_(g[r])
-            else:
-                dist.all_reduce(self.sums, op=dist.ReduceOp.SUM)
-            s2m.batch_iter_apply(self.sums.data_ptr())
+        max_iters = hs[0].cfg.max_iters
+        for it in range(max_iters):                                  # MO:1848
+            for k, h in enumerate(hs):
+                if not live[k]:
+                    continue
+                if work[k] is not None:
+                    work[k].wait()                                   # the stream waits, the host does not
+                h.batch_iter_apply(self.sums[k].data_ptr())          # MO:1784-1835 from the global sums
+                # MO:1857-1858 for every scan of the group.  Every rank solves the same sums, so every
+                # rank sees the same counts and stops issuing collectives at the same iteration.
+                chk = it - self.lookahead
+                if (chk >= 0 and h.batch_poll_active(chk) == 0) or it + 1 >= max_iters:
+                    live[k] = False
+                    continue
+                h.batch_iter_partial(self.sums[k].data_ptr())        # next iteration of this group ...
+                work[k] = self._reduce(k)                            # ... its all-reduce overlaps the other group
             iters += 1
-            # MO:1857-1858 for every scan.  Every rank solves the same sums, so every rank sees the
-            # same count and leaves the loop at the same iteration (the collectives stay matched).
-            chk = it - self.lookahead
-            if chk >= 0 and s2m.batch_poll_active(chk) == 0:
+            if not any(live):
                 break
         return iters
+
+    def results(self, with_results=True):
+        poses, res = [], []
+        for (a, b), h in zip(self.split, self.handles):
+            p, r = h.batch_results(with_results)
+            poses.append(p)
+            if with_results:
+                res.extend(list(r))
+        return np.concatenate(poses), (res if with_results else None)
+
+    def close(self):
+        for h in self.handles:
+            h.close()

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q, deterministic):
+def _worker(rank, world, port, q, deterministic, mode="map", groups=2):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -33,12 +33,12 @@ def _worker(rank, world, port, q, deterministic):
         case = synth.make_case("vlp16", n_keyframes=6, seed=11, device="cpu", n_queries=3)
         scans = [qq["scan"] for qq in case["queries"]] + [case["queries"][0]["scan"][:25]]
         poses0 = np.stack([qq["pose_init"] for qq in case["queries"]] + [case["queries"][0]["pose_init"]])
-        s2m = pkg.ScanToMap(device_id=0)
-        runner = mg.ShardedRunner(s2m, case["map"], rank, world, dist, torch, deterministic=deterministic)
-        s2m.batch_upload(scans)
-        s2m.batch_set_poses(poses0)
+        runner = mg.ShardedRunner(pkg, case["map"], rank, world, dist, torch, mode=mode, groups=groups,
+                                  deterministic=deterministic, device_id=0)
+        runner.upload(scans)
+        runner.set_poses(poses0)
         n_it = runner.run()
-        poses, res = s2m.batch_results()
+        poses, res = runner.results()
         out = {"poses": poses, "iters": [r.iters for r in res], "status": [r.status for r in res],
                "deg": [r.is_degenerate for r in res], "n_it": n_it, "n_shard": len(runner.idx), "n_map": len(case["map"])}
         if rank == 0:
@@ -50,19 +50,19 @@ def _worker(rank, world, port, q, deterministic):
             out["ref_iters"] = [r.iters for r in rr]
             out["ref_status"] = [r.status for r in rr]
             ref.close()
-        s2m.close()
+        runner.close()
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("deterministic", [False, True])
-def test_two_rank_sharded_map_matches_unsharded(deterministic):
+@pytest.mark.parametrize("deterministic,mode,groups", [(False, "map", 2), (True, "map", 1), (False, "scan", 2), (True, "scan", 3)])
+def test_two_rank_sharded_map_matches_unsharded(deterministic, mode, groups):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, deterministic)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, deterministic, mode, groups)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in procs)
@@ -73,7 +73,8 @@ def test_two_rank_sharded_map_matches_unsharded(deterministic):
     np.testing.assert_array_equal(a["poses"], b["poses"])            # every rank solves the same sums
     assert a["iters"] == b["iters"] == a["ref_iters"]
     assert a["status"] == b["status"] == a["ref_status"]
-    assert a["n_shard"] < a["n_map"] and b["n_shard"] < b["n_map"]
+    if mode == "map":
+        assert a["n_shard"] < a["n_map"] and b["n_shard"] < b["n_map"]
     np.testing.assert_allclose(a["poses"][:, 3:], a["ref_poses"][:, 3:], atol=1e-5)
     np.testing.assert_allclose(a["poses"][:, :3], a["ref_poses"][:, :3], atol=1e-6)
     assert a["status"][-1] == 1                                       # the too-small scan is skipped (MO:1844)

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Per-rank cost of one GN-iteration launch under the two N>1 partitions, measured on ONE GPU
+(no collective): weak scaling = 512*N scans in the job, rank r does its share.
+   python tools/shard_cost.py /tmp/c512.npz"""
+import importlib, sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+pkg = importlib.import_module("lio-slam_amd")
+mg = importlib.import_module("lio-slam_amd.multigpu")
+z = np.load(sys.argv[1])
+offs = np.concatenate([[0], np.cumsum(z["lens"])])
+scans1 = [np.ascontiguousarray(z["scans"][offs[i]:offs[i + 1]]) for i in range(len(z["lens"]))]
+map_xyz, poses1 = z["map"], z["poses0"]
+
+
+def one(mode, world, rank):
+    s2m = pkg.ScanToMap(profile=1, max_iters=2)
+    if mode == "map":
+        plan = mg.plan_shards(map_xyz, world)
+        idx = mg.shard_points(map_xyz, plan, rank)
+        s2m.set_map(np.ascontiguousarray(map_xyz[idx]))
+        s2m.set_global_grid([float(v) for v in plan["origin"]], [int(v) for v in plan["dims"]])
+        s2m.set_shard(plan["axis"], int(plan["bounds"][rank]), int(plan["bounds"][rank + 1]))
+    else:
+        s2m.set_map(map_xyz)
+        s2m.set_scan_shard(rank, world)
+    s2m.batch_upload(scans1 * world)
+    s2m.batch_set_poses(np.tile(poses1, (world, 1)))
+    sums = torch.zeros((len(scans1) * world, 32), dtype=torch.float64, device="cuda")
+    ms = []
+    for rep in range(3):
+        s2m.batch_begin()
+        s2m.batch_iter_partial(sums.data_ptr())
+        s2m.batch_sync()
+        s2m.batch_results(False)
+        ms.append(s2m.profile().launch_ms[0])
+    s2m.close()
+    return min(ms)
+
+
+base = one("scan", 1, 0)
+print(f"N=1: {base:.3f} ms per launch (512 scans)")
+for mode in ("map", "scan"):
+    for world in (2, 4, 8):
+        t = [one(mode, world, r) for r in sorted({0, world // 2, world - 1})]
+        print(f"{mode:4s} N={world}: slowest sampled rank {max(t):.3f} ms for {512 * world} scans -> kernel-only weak-scaling efficiency {base / max(t):.2f}")
