@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--xcd", type=int, default=1)
     ap.add_argument("--tile", type=float, default=0.0)
     ap.add_argument("--lookahead", type=int, default=0)
+    ap.add_argument("--graph", type=int, default=12, help="replay a hipGraph of this many GN iterations per launch unit (0 = eager launches)")
     ap.add_argument("--shard", choices=["map", "scan"], default="scan",
                     help="N>1: map = slabs of the map + halo, owner-computes (north_star); scan = map replicated, workgroups of every scan dealt round-robin")
     ap.add_argument("--lawnmower", action="store_true", help="keyframes on a lawn-mower path inside a 50 m radius (configs[3])")
@@ -200,7 +201,7 @@ def main():
         f"B={B} gen {time.time() - t0:.1f}s")
 
     # -------------------------------------------------------------- engine
-    kcfg = dict(device_id=local_rank, profile=1, lookahead=args.lookahead, kernel_variant=args.variant,
+    kcfg = dict(device_id=local_rank, profile=1, use_graph=1 if args.graph else 0, graph_iters=max(args.graph, 1), lookahead=args.lookahead, kernel_variant=args.variant,
                 use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile)
     if world > 1:
         runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2, **kcfg)
@@ -258,10 +259,15 @@ def main():
         poses, results = s2m.batch_results(with_results=True)
         prof = s2m.profile()
         iters = np.array([r.iters for r in results])
-        n_launch = prof.n_launches
-        lms = np.array(prof.launch_ms[:n_launch], dtype=np.float64)
+        # a unit = one launch (eager) or one replay of a captured chunk of unit_iters launches; the
+        # average launch duration and the average algorithmic bytes are both taken over ALL launches
+        # of k_s2m_iterate, like the rocprofv3 kernel-trace average
+        ui = max(prof.unit_iters, 1)
+        n_launch = prof.n_units * ui
+        unit_ms = np.array(prof.launch_ms[:prof.n_units], dtype=np.float64)
+        lms = np.repeat(unit_ms / ui, ui)
         pts_per_launch = np.array([int(n_s[iters > i].sum()) for i in range(n_launch)], dtype=np.float64)
-    live = pts_per_launch > 0
+    live = lms > 0
     bytes_per_launch = BYTES_PER_POINT_ITER * pts_per_launch[live].mean() if live.any() else 0.0
     ms_per_launch = float(lms[live].mean()) if live.any() else float("nan")
     achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if live.any() else 0.0
@@ -280,8 +286,9 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": f"{args.sensor} 64x1800 synthetic street-canyon scans vs {args.keyframes}-keyframe map "
-                        f"(BASELINE.json headline / configs[4] batched form)",
+            "workload": f"{args.sensor} {synth.SENSORS[args.sensor][0]}x{synth.SENSORS[args.sensor][1]} synthetic street-canyon "
+                        f"scans vs {args.keyframes}-keyframe map (BASELINE.json headline = hdl64 64x1800 vs 200; "
+                        f"configs[4] batched form)",
             "scans_per_step": B, "N_s_mean": float(n_s.mean()), "N_m": int(len(map_xyz)),
             "gn_iters_mean": float(iters.mean()), "gn_iters_max": int(iters.max()),
             "parallelism": "single GPU" if world == 1 else
@@ -294,7 +301,7 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": "k_s2m_iterate", "ms_per_launch": ms_per_launch,
-            "launches_per_step": int(live.sum()), "algorithmic_bytes_per_launch": bytes_per_launch,
+            "launches_per_step": int(live.sum()), "launches_per_graph_replay": int(args.graph), "algorithmic_bytes_per_launch": bytes_per_launch,
             "launch_ms": [round(float(v), 4) for v in lms], "launch_points": [int(v) for v in pts_per_launch],
         },
         "map_build_ms": prof0.map_build_ms, "map_upload_ms": prof0.map_upload_ms,

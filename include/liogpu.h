@@ -76,6 +76,10 @@ typedef struct lio_s2m_config {
                                 scan visits (2k+1)^3 cells, map rows are replicated (2k+1)^2 x */
     int32_t xcd_remap;       /* 1 (default) = XCD-aware workgroup order (L2 locality only)  */
     float   tile_size;       /* edge of the upload-time sort tiles in metres (0 = 4 m)      */
+    int32_t use_graph;       /* 1 = replay a hipGraph of `graph_iters` captured GN iterations
+                                per unit of the launch loop (BASELINE config 5); ignored when
+                                record_corr_iter or the diagnostic profile=2 is set        */
+    int32_t graph_iters;     /* iterations per captured chunk (default 4)                   */
 } lio_s2m_config;
 
 /* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in
@@ -97,8 +101,10 @@ typedef struct lio_s2m_profile {
     float   map_build_ms;      /* last set_map: H2D excluded, grid build kernels only     */
     float   map_upload_ms;     /* last set_map: wall time of staging + H2D                */
     int32_t n_launches;        /* GN-iteration launches of the last run                   */
-    float   launch_ms[LIO_MAX_ITERS]; /* device time of each (profile=1)                 */
-    int32_t launch_active[LIO_MAX_ITERS]; /* scans that took part in each launch           */
+    int32_t n_units;           /* launch units: single launches, or graph replays          */
+    int32_t unit_iters;        /* launches per unit (1, or cfg.graph_iters)                */
+    float   launch_ms[LIO_MAX_ITERS]; /* device time of each unit (profile=1)            */
+    int32_t launch_active[LIO_MAX_ITERS]; /* scans in the first launch of each unit       */
     int64_t point_iters;       /* scan points processed by active scans over the run      */
     int64_t n_map;             /* resident map points                                     */
     int64_t n_cells;           /* grid cells                                              */

@@ -32,6 +32,7 @@ class S2MConfig(C.Structure):
         ("max_scan_pts", C.c_int32), ("record_corr_iter", C.c_int32), ("kernel_variant", C.c_int32),
         ("profile", C.c_int32), ("lookahead", C.c_int32), ("use_lds", C.c_int32), ("sort_scan", C.c_int32),
         ("cell_div", C.c_int32), ("xcd_remap", C.c_int32), ("tile_size", C.c_float),
+        ("use_graph", C.c_int32), ("graph_iters", C.c_int32),
     ]
 
 
@@ -48,6 +49,7 @@ class S2MResult(C.Structure):
 class S2MProfile(C.Structure):
     _fields_ = [
         ("map_build_ms", C.c_float), ("map_upload_ms", C.c_float), ("n_launches", C.c_int32),
+        ("n_units", C.c_int32), ("unit_iters", C.c_int32),
         ("launch_ms", C.c_float * LIO_MAX_ITERS), ("launch_active", C.c_int32 * LIO_MAX_ITERS),
         ("point_iters", C.c_int64),
         ("n_map", C.c_int64), ("n_cells", C.c_int64),

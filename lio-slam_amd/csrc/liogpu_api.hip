@@ -90,6 +90,13 @@ struct lio_s2m_handle {
     int* d_perm = nullptr; size_t cap_perm = 0;
     bool sorted = false;
     long long* d_stamps = nullptr; size_t cap_stamps = 0;
+    // hipGraph-captured chunk of GN iterations (cfg.use_graph)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_dirty = true;
+    int graph_chunk = 0, graph_blocks = 0, graph_ppt = 0;
+    LioIterParams graph_params;       // arguments the cached graph was captured with
+    int units_this_run = 0, unit_iters = 1;
 
     // correspondence record (debug / parity)
     unsigned char* d_rec_flag = nullptr; size_t cap_rec_flag = 0;
@@ -144,6 +151,8 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->cell_div = 2;
     c->xcd_remap = 1;
     c->tile_size = 0.0f;
+    c->use_graph = 0;
+    c->graph_iters = 4;
     c->sort_scan = 1;
 }
 
@@ -212,6 +221,8 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
         (void)hipEventDestroy(h->ev_map[0]);
         (void)hipEventDestroy(h->ev_map[1]);
     }
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -223,6 +234,7 @@ extern "C" int lio_s2m_set_stream(lio_s2m_handle* h, void* hip_stream)
     if (h->own_stream && h->stream) HIPCHK(hipStreamDestroy(h->stream));
     h->stream = (hipStream_t)hip_stream;
     h->own_stream = false;
+    h->graph_dirty = true;
     return LIO_OK;
 }
 
@@ -309,6 +321,7 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
     h->prof.n_cells = g.n_cells;
     h->n_map = n;
     h->has_map = true;
+    h->graph_dirty = true;
     return LIO_OK;
 }
 
@@ -376,6 +389,7 @@ extern "C" int lio_s2m_set_shard(lio_s2m_handle* h, int32_t axis, int32_t lo, in
     h->shard.gdim = h->gdims[axis];
     h->shard.lo = lo;
     h->shard.hi = hi;
+    h->graph_dirty = true;
     return LIO_OK;
 }
 
@@ -521,6 +535,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     HIPCHK(hipGetLastError());
     h->poses_set = false;
     h->ran = false;
+    h->graph_dirty = true;
     return LIO_OK;
 }
 
@@ -588,7 +603,30 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->c, h->d_active, h->stream);
     h->launches_this_run = 0;
+    h->units_this_run = 0;
+    h->unit_iters = 1;
     h->ran = true;
+    return LIO_OK;
+}
+
+// (Re)capture `chunk` consecutive GN-iteration launches into a hipGraph.  Every launch has the
+// same arguments -- all per-iteration state lives in device memory -- so one executable graph
+// serves the whole loop; scans that are done turn their workgroups into immediate exits.
+static int lio_graph_prepare(lio_s2m_handle* h, const LioIterParams& P, int chunk)
+{
+    // the cached graph stays valid as long as the kernel arguments and the launch geometry are the same
+    if (h->graph_exec && h->graph_chunk == chunk && h->graph_blocks == h->n_blocks && h->graph_ppt == h->ppt &&
+        memcmp(&h->graph_params, &P, sizeof(P)) == 0)
+        return LIO_OK;
+    if (h->graph_exec) { HIPCHK(hipGraphExecDestroy(h->graph_exec)); h->graph_exec = nullptr; }
+    if (h->graph) { HIPCHK(hipGraphDestroy(h->graph)); h->graph = nullptr; }
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < chunk; ++i) lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
+    HIPCHK(hipStreamEndCapture(h->stream, &h->graph));
+    HIPCHK(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+    h->graph_chunk = chunk; h->graph_blocks = h->n_blocks; h->graph_ppt = h->ppt;
+    memcpy(&h->graph_params, &P, sizeof(P));
+    h->graph_dirty = false;
     return LIO_OK;
 }
 
@@ -597,29 +635,42 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
     int rc = lio_s2m_batch_begin(h);
     if (rc != LIO_OK) return rc;
     LioIterParams P;
+    memset(&P, 0, sizeof(P));          // (padding bytes take part in the graph-cache comparison)
     lio_fill_params(h, P, nullptr);
     const bool prof = h->cfg.profile != 0;
-    // The GN loop (MO:1848-1859) runs ahead of the device by `lookahead`
-    // launches: after every launch the count of still-iterating scans is copied
-    // to pinned memory; launch i is only enqueued once the count after launch
-    // i-1-lookahead is known to be non-zero.  lookahead 0 never enqueues an
-    // empty launch; larger values keep the queue fed for small batches.
+    // The GN loop (MO:1848-1859) runs ahead of the device by `lookahead` launches: after every
+    // launch (or graph replay) the count of still-iterating scans is copied to pinned memory;
+    // unit i is only enqueued once the count after unit i-1-lookahead is known to be non-zero.
+    // lookahead 0 never enqueues an empty launch; larger values keep the queue fed for small batches.
     int look = h->cfg.lookahead;
     if (look < 0) look = (h->total_pts >= 200000) ? 0 : 2;
+    // use_graph: a unit is one replay of a captured chunk of `graph_iters` iterations
+    const bool graph = h->cfg.use_graph != 0 && h->cfg.profile != 2 && h->cfg.record_corr_iter < 0 && h->n_blocks > 0;
+    int chunk = 1;
+    if (graph) {
+        chunk = h->cfg.graph_iters > 0 ? h->cfg.graph_iters : 4;
+        if (chunk > h->cfg.max_iters) chunk = h->cfg.max_iters;
+        if ((rc = lio_graph_prepare(h, P, chunk)) != LIO_OK) return rc;
+        if (h->cfg.lookahead < 0) look = 0;              // a chunk already is a run-ahead of `chunk` launches
+    }
+    const int n_units = (h->cfg.max_iters + chunk - 1) / chunk;
     int launched = 0;
-    for (int it = 0; it < h->cfg.max_iters; ++it) {      // MO:1848
-        const int chk = it - 1 - look;
+    for (int u = 0; u < n_units && u < LIO_MAX_ITERS; ++u) {          // MO:1848
+        const int chk = u - 1 - look;
         if (chk >= 0) {
             HIPCHK(hipEventSynchronize(h->ev_chk[chk]));
             if (h->h_active[chk] == 0) break;
         }
-        if (prof) HIPCHK(hipEventRecord(h->ev_beg[it], h->stream));
-        lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
-        if (prof) HIPCHK(hipEventRecord(h->ev_end[it], h->stream));
-        HIPCHK(hipMemcpyAsync(&h->h_active[it], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipEventRecord(h->ev_chk[it], h->stream));
-        ++launched;
+        if (prof) HIPCHK(hipEventRecord(h->ev_beg[u], h->stream));
+        if (graph) HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
+        else lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
+        if (prof) HIPCHK(hipEventRecord(h->ev_end[u], h->stream));
+        HIPCHK(hipMemcpyAsync(&h->h_active[u], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->ev_chk[u], h->stream));
+        launched += chunk;
+        h->units_this_run = u + 1;
     }
+    h->unit_iters = chunk;
     h->launches_this_run = launched;
     HIPCHK(hipGetLastError());
     return LIO_OK;
@@ -640,6 +691,7 @@ extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
     lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
     if (prof) HIPCHK(hipEventRecord(h->ev_end[it], h->stream));
     h->launches_this_run++;
+    h->units_this_run = h->launches_this_run;
     HIPCHK(hipGetLastError());
     return LIO_OK;
 }
@@ -726,21 +778,25 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
     h->prof.point_iters = pit;
     h->prof.n_launches = h->launches_this_run;
     for (int i = 0; i < LIO_MAX_ITERS; ++i) { h->prof.launch_ms[i] = 0.0f; h->prof.launch_active[i] = 0; }
-    for (int i = 0; i < h->launches_this_run && i < LIO_MAX_ITERS; ++i) {
-        // scans still iterating BEFORE launch i = those that took part in it
+    // launch_ms[u] = device time of launch unit u (one launch, or one graph replay of unit_iters
+    // launches); launch_active[u] = scans that took part in the unit's first launch
+    const int n_units = h->units_this_run > 0 ? h->units_this_run : h->launches_this_run;
+    for (int u = 0; u < n_units && u < LIO_MAX_ITERS; ++u) {
         int act = 0;
         for (int s = 0; s < h->n_scans; ++s) {
             const LioScanState& st = h->h_state[s];
             const int ran = st.status == 1 ? 0 : (st.status == 2 ? 1 : st.iter);
-            if (i < ran) ++act;
+            if (u * h->unit_iters < ran) ++act;
         }
-        h->prof.launch_active[i] = act;
-        if (h->cfg.profile) {
+        h->prof.launch_active[u] = act;
+        if (h->cfg.profile && h->units_this_run > 0) {
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, h->ev_beg[i], h->ev_end[i]) != hipSuccess) ms = -1.0f;
-            h->prof.launch_ms[i] = ms;
+            if (hipEventElapsedTime(&ms, h->ev_beg[u], h->ev_end[u]) != hipSuccess) ms = -1.0f;
+            h->prof.launch_ms[u] = ms;
         }
     }
+    h->prof.n_units = n_units;
+    h->prof.unit_iters = h->unit_iters;
     return LIO_OK;
 }
 

@@ -185,3 +185,27 @@ def test_exact_ties_and_coincident_points(pkg, oracle):
         assert np.array_equal(nn, nn_o)
         assert np.array_equal(flag, flag_o)
         assert (nn_o[:, 4] >= 0).sum() > 100
+
+
+@pytest.mark.parametrize("graph_iters", [1, 4, 7, 30])
+def test_hipgraph_loop_is_identical(pkg, small_case, graph_iters):
+    """BASELINE config 5: the GN loop replayed from a captured hipGraph chunk gives the same bits
+    as the eager launch loop, for single scans and for ragged batches, also across re-uploads."""
+    qs = small_case["queries"]
+    scans = [q["scan"] for q in qs] + [qs[0]["scan"][:20], qs[1]["scan"][::2]]
+    poses0 = np.stack([q["pose_init"] for q in qs] + [qs[0]["pose_init"], qs[1]["pose_init"]])
+    eager = pkg.ScanToMap()
+    eager.set_map(small_case["map"])
+    eager.batch_upload(scans); eager.batch_set_poses(poses0); eager.batch_run()
+    pe, re_ = eager.batch_results()
+    g = pkg.ScanToMap(use_graph=1, graph_iters=graph_iters)
+    g.set_map(small_case["map"])
+    for rep in range(2):                                   # second round replays the cached graph
+        g.batch_upload(scans); g.batch_set_poses(poses0); g.batch_run()
+        pg, rg = g.batch_results()
+        np.testing.assert_array_equal(pg, pe)
+        assert [r.iters for r in rg] == [r.iters for r in re_]
+        assert [r.status for r in rg] == [r.status for r in re_]
+    p1, r1, _ = g.scan2MapOptimization(qs[2]["scan"], qs[2]["pose_init"])      # new geometry -> re-capture
+    np.testing.assert_array_equal(p1, pe[2])
+    eager.close(); g.close()
