@@ -83,12 +83,20 @@ __global__ void k_map_bbox(const float* __restrict__ x, const float* __restrict_
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
         }
     }
+    // one set of atomics per workgroup (six hot words: per-wave atomics serialise)
+    __shared__ float s_mn[4][3], s_mx[4][3];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&bbox[a], lio_f2ord(mn[a]));
-            atomicMax(&bbox[3 + a], lio_f2ord(mx[a]));
-        }
+        for (int a = 0; a < 3; ++a) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float lo = s_mn[0][a], hi = s_mx[0][a];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fminf(lo, s_mn[w][a]); hi = fmaxf(hi, s_mx[w][a]); }
+        atomicMin(&bbox[a], lio_f2ord(lo));
+        atomicMax(&bbox[3 + a], lio_f2ord(hi));
     }
 }
 
@@ -235,13 +243,15 @@ LIO_DEV void lio_nbr_store(float* __restrict__ base, int pos, float x, float y, 
 // stays filled with dummies), so row lists start 4-aligned and an aligned group of four never
 // straddles two row lists -- neighbouring rows hold copies of the same map points, and a candidate
 // seen twice would corrupt the top-5.
-__global__ void k_map_nbr_pad_rows(LioGrid g, int* __restrict__ nbr_count)
+__global__ __launch_bounds__(256) void k_map_nbr_pad_rows(LioGrid g, int* __restrict__ nbr_count)
 {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // one wave per row
     if (row >= g.ny * g.nz) return;
     int s = 0;
-    for (int x = 0; x < g.nx; ++x) s += nbr_count[row * g.nx + x];
-    nbr_count[row * g.nx + g.nx - 1] += (4 - (s & 3)) & 3;
+    for (int x = lane; x < g.nx; x += 64) s += nbr_count[row * g.nx + x];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) nbr_count[row * g.nx + g.nx - 1] += (4 - (s & 3)) & 3;
 }
 
 __global__ void k_map_nbr_fill(float4* __restrict__ nbr_pts, int n_rec4)
@@ -923,8 +933,9 @@ void lio_launch_aos_to_soa(const void* src, size_t stride, int n, float* x, floa
 
 void lio_launch_map_bbox(const float* x, const float* y, const float* z, int n, unsigned* bbox, hipStream_t s)
 {
-    int blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (n + 1023) / 1024;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_map_bbox, dim3(blocks), dim3(256), 0, s, x, y, z, n, bbox);
 }
 
@@ -950,7 +961,7 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
     // replicated neighbourhood rows (9x): used by the default candidate scan
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
     hipLaunchKernelGGL(k_map_nbr_count, dim3(nb), dim3(256), 0, s, g, cell_of, n, cell_count);
-    hipLaunchKernelGGL(k_map_nbr_pad_rows, dim3((g.ny * g.nz + 255) / 256), dim3(256), 0, s, g, cell_count);
+    hipLaunchKernelGGL(k_map_nbr_pad_rows, dim3((g.ny * g.nz + 3) / 4), dim3(256), 0, s, g, cell_count);
     lio_launch_exclusive_scan(cell_count, g.n_cells, tile_sums, nbr_start, s);
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
     {

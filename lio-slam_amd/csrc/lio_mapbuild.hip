@@ -11,6 +11,7 @@
 
 #include "../../include/liogpu.h"
 #include "lio_kernels.h"
+#include "lio_pool.h"
 #include "lio_device_math.h"
 
 int lio_fail_ext(int code, const char* what, hipError_t e);                    // liogpu_api.hip
@@ -88,9 +89,19 @@ __global__ void k_vox_bbox(const float4* __restrict__ p, int n, unsigned* __rest
             mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
         }
+    __shared__ float s_mn[4][3], s_mx[4][3];          // one set of atomics per workgroup
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { atomicMin(&bbox[a], lio_f2ord2(mn[a])); atomicMax(&bbox[3 + a], lio_f2ord2(mx[a])); }
+        for (int a = 0; a < 3; ++a) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float lo = s_mn[0][a], hi = s_mx[0][a];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fminf(lo, s_mn[w][a]); hi = fmaxf(hi, s_mx[w][a]); }
+        atomicMin(&bbox[a], lio_f2ord2(lo));
+        atomicMax(&bbox[3 + a], lio_f2ord2(hi));
+    }
 }
 
 struct LioVoxGrid { float inv; int min_b0, min_b1, min_b2, mul1, mul2, n_keys; };
@@ -191,12 +202,7 @@ __global__ void k_xyzi4_to_aos(const float4* __restrict__ src, int n, unsigned c
 }
 
 namespace {
-struct Buf {
-    void* p = nullptr;
-    ~Buf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    template <typename T> T* as() { return (T*)p; }
-};
+typedef LioTemp Buf;         // temporaries come from the recycling pool (lio_pool.h)
 
 float ord2f(unsigned u)
 {
@@ -216,7 +222,7 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, Buf& out, int* n_ou
     HIPCHK(bbox.alloc(6 * sizeof(unsigned)));
     const unsigned init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
     HIPCHK(hipMemcpyAsync(bbox.p, init, sizeof(init), hipMemcpyHostToDevice, s));
-    int nbb = (n + 255) / 256; if (nbb > 2048) nbb = 2048;
+    int nbb = (n + 1023) / 1024; if (nbb > 512) nbb = 512; if (nbb < 1) nbb = 1;
     hipLaunchKernelGGL(k_vox_bbox, dim3(nbb), dim3(256), 0, s, d_in, n, bbox.as<unsigned>());
     unsigned hb[6];
     HIPCHK(hipMemcpyAsync(hb, bbox.p, sizeof(hb), hipMemcpyDeviceToHost, s));

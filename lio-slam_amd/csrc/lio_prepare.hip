@@ -10,6 +10,7 @@
 #include <string>
 
 #include "../../include/liogpu.h"
+#include "lio_pool.h"
 
 #define LIO_DEV __device__ __forceinline__
 
@@ -250,14 +251,7 @@ extern "C" void lio_deskew_default_config(lio_deskew_config* c)
     c->device_id = 0;
 }
 
-namespace {
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    template <typename T> T* as() { return (T*)p; }
-};
-}
+typedef LioTemp DevBuf;      // temporaries come from the recycling pool (lio_pool.h)
 
 extern "C" int lio_deskew(const lio_deskew_config* cfg, const void* pts, size_t n, size_t stride,
                           double time_scan_cur,

@@ -11,7 +11,9 @@
 
 #include "../../include/liogpu.h"
 #include "lio_kernels.h"
+#include "lio_pool.h"
 #include "lio_types.h"
+#include <mutex>
 
 static thread_local std::string g_last_error;
 
@@ -968,4 +970,75 @@ extern "C" int lio_s2m_debug_stamps(lio_s2m_handle* h, long long* out, size_t ca
         if (hipMemcpy(out, h->d_stamps, n * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     }
     return h->n_blocks;
+}
+
+// ------------------------------------------------------------- temporary pool
+namespace {
+struct PoolBlock { void* p; size_t cap; int device; bool busy; };
+std::mutex g_pool_mu;
+std::vector<PoolBlock> g_pool;
+size_t g_pool_bytes = 0;
+const size_t kPoolLimit = (size_t)8 << 30;      // idle + busy bytes kept before idle blocks are dropped
+}
+
+hipError_t lio_pool_acquire(void** p, size_t bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_pool.size(); ++i) {
+        const PoolBlock& b = g_pool[i];
+        if (!b.busy && b.device == dev && b.cap >= bytes && b.cap <= 2 * bytes + 4096 &&
+            (best < 0 || b.cap < g_pool[best].cap))
+            best = (int)i;
+    }
+    if (best >= 0) { g_pool[best].busy = true; *p = g_pool[best].p; return hipSuccess; }
+    if (g_pool_bytes + bytes > kPoolLimit) {            // drop idle blocks before growing further
+        for (size_t i = 0; i < g_pool.size();) {
+            if (!g_pool[i].busy) {
+                (void)hipSetDevice(g_pool[i].device);
+                (void)hipFree(g_pool[i].p);
+                g_pool_bytes -= g_pool[i].cap;
+                g_pool[i] = g_pool.back();
+                g_pool.pop_back();
+            } else {
+                ++i;
+            }
+        }
+        (void)hipSetDevice(dev);
+    }
+    const size_t cap = bytes + bytes / 4 + 256;
+    e = hipMalloc(p, cap);
+    if (e != hipSuccess) return e;
+    g_pool.push_back({ *p, cap, dev, true });
+    g_pool_bytes += cap;
+    return hipSuccess;
+}
+
+void lio_pool_release(void* p)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (PoolBlock& b : g_pool)
+        if (b.p == p) { b.busy = false; return; }
+}
+
+void lio_pool_trim(void)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (size_t i = 0; i < g_pool.size();) {
+        if (!g_pool[i].busy) {
+            (void)hipSetDevice(g_pool[i].device);
+            (void)hipFree(g_pool[i].p);
+            g_pool_bytes -= g_pool[i].cap;
+            g_pool[i] = g_pool.back();
+            g_pool.pop_back();
+        } else {
+            ++i;
+        }
+    }
+    (void)hipSetDevice(dev);
 }

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Driver for profiling the upstream/feeder kernels (K1 deskew, K2 curvature, K6/K7 map
+assembly, voxel filter) on headline-sized inputs.
+   python tools/prof_feeders.py gen /tmp/feed.npz      # synthetic inputs (GPU ray caster), not profiled
+   rocprofv3 --kernel-trace --stats ... -- python tools/prof_feeders.py run /tmp/feed.npz
+"""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("lio-slam_amd")
+mode, path = sys.argv[1], sys.argv[2]
+if mode == "gen":
+    synth = importlib.import_module("lio-slam_amd.synth")
+    boxes = synth.make_scene(synth.BASE_SEED, length=260.0)
+    kfs = synth.keyframe_poses(200, seed=synth.BASE_SEED)
+    sc = synth.cast_scan(boxes, kfs[100], "hdl64", seed=1, omega=(0.05, -0.03, 0.4))
+    clouds, lens = [], []
+    for k, kp in enumerate(kfs):
+        s = synth.cast_scan(boxes, kp, "hdl64", seed=1000 + k)
+        ds = synth.voxel_downsample(s["xyz"], 0.4)
+        clouds.append(np.concatenate([ds, np.zeros((len(ds), 1), np.float32)], 1)); lens.append(len(ds))
+    np.savez(path, xyz=sc["xyz"], intensity=sc["intensity"], ring=sc["ring"], time=sc["time"], range=sc["range"],
+             kf=np.concatenate(clouds), kf_lens=np.array(lens), kf_poses=kfs.astype(np.float32))
+    print("generated", len(sc["xyz"]), "raw points,", sum(lens), "keyframe points")
+else:
+    z = np.load(path)
+    reps = 5
+    t0 = 10.0
+    stamp = t0 - 0.01 + np.arange(70) * 0.002
+    imu = pkg.imu_deskew_info(stamp, np.tile(np.array([[0.05, -0.03, 0.4]]), (70, 1)), t0, t0 + 0.1)
+    rec = pkg.pack_xyzirt(z["xyz"], z["intensity"], z["ring"], z["time"])
+    d = pkg.deskew_default_config(N_SCAN=64, point_filter_num=1, lidarMinFront=0, lidarMinBack=0, lidarMinLeft=0, lidarMinRight=0)
+    out = pkg.deskew(d, rec, t0, imu)              # warm-up: context creation, code-object load, pool
+    t = time.perf_counter()
+    for _ in range(reps):
+        out = pkg.deskew(d, rec, t0, imu)
+    print(f"K1 deskew: {len(rec)} -> {len(out)} points, {1e3 * (time.perf_counter() - t) / reps:.3f} ms/call incl. H2D+D2H")
+    pkg.curvature(z["range"])
+    t = time.perf_counter()
+    for _ in range(reps):
+        curv = pkg.curvature(z["range"])[0]
+    print(f"K2 curvature: {len(curv)} ranges, {1e3 * (time.perf_counter() - t) / reps:.3f} ms/call incl. H2D+D2H")
+    pkg.voxel_grid(out, 0.4)
+    t = time.perf_counter()
+    for _ in range(reps):
+        ds, _ = pkg.voxel_grid(out, 0.4)
+    print(f"K7 voxel 0.4 m: {len(out)} -> {len(ds)} points, {1e3 * (time.perf_counter() - t) / reps:.3f} ms/call incl. H2D+D2H")
+    offs = np.concatenate([[0], np.cumsum(z["kf_lens"])])
+    store = pkg.KeyframeStore()
+    ids = [store.add(z["kf"][offs[i]:offs[i + 1]]) for i in range(len(z["kf_lens"]))]
+    s2m = pkg.ScanToMap()
+    store.assemble(ids, z["kf_poses"], 0.5, s2m=s2m, want_output=False)
+    t = time.perf_counter()
+    for _ in range(reps):
+        _, n_out, _ = store.assemble(ids, z["kf_poses"], 0.5, s2m=s2m, want_output=False)
+    print(f"K6+K7 map assembly: {int(offs[-1])} -> {n_out} points + grid build, {1e3 * (time.perf_counter() - t) / reps:.3f} ms/call (resident keyframes)")
