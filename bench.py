@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--sort", type=int, default=1)
     ap.add_argument("--celldiv", type=int, default=2)
     ap.add_argument("--xcd", type=int, default=1)
+    ap.add_argument("--sortbatch", type=int, default=1)
     ap.add_argument("--tile", type=float, default=0.0)
     ap.add_argument("--lookahead", type=int, default=0)
     ap.add_argument("--graph", type=int, default=12, help="replay a hipGraph of this many GN iterations per launch unit (0 = eager launches)")
@@ -202,7 +203,7 @@ def main():
 
     # -------------------------------------------------------------- engine
     kcfg = dict(device_id=local_rank, profile=1, use_graph=1 if args.graph else 0, graph_iters=max(args.graph, 1), lookahead=args.lookahead, kernel_variant=args.variant,
-                use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile)
+                use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch)
     if world > 1:
         runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2, **kcfg)
         runner.upload(scans)

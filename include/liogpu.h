@@ -80,6 +80,8 @@ typedef struct lio_s2m_config {
                                 per unit of the launch loop (BASELINE config 5); ignored when
                                 record_corr_iter or the diagnostic profile=2 is set        */
     int32_t graph_iters;     /* iterations per captured chunk (default 4)                   */
+    int32_t sort_batch;      /* 1 (default) = order the workgroups of a batch by the scans'
+                                positions (L2 locality only; results are unaffected)       */
 } lio_s2m_config;
 
 /* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in

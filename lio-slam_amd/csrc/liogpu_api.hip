@@ -14,6 +14,7 @@
 #include "lio_pool.h"
 #include "lio_types.h"
 #include <mutex>
+#include <algorithm>
 
 static thread_local std::string g_last_error;
 
@@ -74,6 +75,8 @@ struct lio_s2m_handle {
     std::vector<LioScanState> h_state;
     std::vector<LioBlockDesc> v_blocks, v_prep;      // launch descriptors (kept alive for async H2D)
     std::vector<LioScanTiles> v_tiles;
+    std::vector<LioBlockDesc> v_blocks_sorted;       // v_blocks re-ordered by scan position (sort_batch)
+    std::vector<int> v_order, v_first, v_first_orig;
     bool defer_sync = false;                         // lio_s2m_register: one sync at the end of the call
     float* d_poses = nullptr; size_t cap_poses = 0;
     LioBlockDesc* d_blocks = nullptr; size_t cap_blocks = 0;
@@ -154,6 +157,7 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->xcd_remap = 1;
     c->tile_size = 0.0f;
     c->use_graph = 0;
+    c->sort_batch = 1;
     c->graph_iters = 4;
     c->sort_scan = 1;
 }
@@ -456,6 +460,9 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
                                   hipMemcpyHostToDevice, h->stream));
         off += n_pts[s];
     }
+    h->v_first_orig.assign((size_t)n_scans + 1, 0);
+    for (const LioBlockDesc& b : blocks) h->v_first_orig[b.scan + 1]++;
+    for (int s = 0; s < n_scans; ++s) h->v_first_orig[s + 1] += h->v_first_orig[s];
     h->n_scans = n_scans;
     h->total_pts = total;
     h->n_blocks = (int)blocks.size();
@@ -548,6 +555,33 @@ extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     HIPCHK(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_scans * 6 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (h->cfg.sort_batch && h->n_scans > 8 && !h->v_blocks.empty()) {
+        // Locality only: order the workgroup list by where the scans ARE (position along the map's
+        // longest axis).  Together with the XCD-aware workgroup order every XCD then streams the
+        // map rows of one stretch of the trajectory, which fit its private 4 MB L2.
+        const float ext[3] = { (float)h->grid.nx, (float)h->grid.ny, (float)h->grid.nz };
+        const int ax = (ext[0] >= ext[1] && ext[0] >= ext[2]) ? 0 : (ext[1] >= ext[2] ? 1 : 2);
+        std::vector<int>& order = h->v_order;
+        order.resize((size_t)h->n_scans);
+        for (int s = 0; s < h->n_scans; ++s) order[s] = s;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](int a, int b) { return poses[a * 6 + 3 + ax] < poses[b * 6 + 3 + ax]; });
+        // v_blocks is grouped by scan in upload order: gather the groups in the new order
+        std::vector<int>& first = h->v_first;
+        first.assign((size_t)h->n_scans + 1, 0);
+        for (const LioBlockDesc& b : h->v_blocks) first[b.scan + 1]++;
+        for (int s = 0; s < h->n_scans; ++s) first[s + 1] += first[s];
+        std::vector<LioBlockDesc>& sorted = h->v_blocks_sorted;
+        sorted.clear();
+        sorted.reserve(h->v_blocks.size());
+        // (v_blocks itself stays in scan order so that the grouping survives repeated calls)
+        for (int k = 0; k < h->n_scans; ++k) {
+            const int s = order[k];
+            // blocks of scan s are the ones whose .scan == s; they are contiguous in the ORIGINAL list
+            for (int i = h->v_first_orig[s]; i < h->v_first_orig[s + 1]; ++i) sorted.push_back(h->v_blocks[i]);
+        }
+        HIPCHK(hipMemcpyAsync(h->d_blocks, sorted.data(), sorted.size() * sizeof(LioBlockDesc), hipMemcpyHostToDevice, h->stream));
+    }
     if (!h->defer_sync) HIPCHK(hipStreamSynchronize(h->stream));
     h->poses_set = true;
     return LIO_OK;
