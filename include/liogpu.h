@@ -59,8 +59,8 @@ typedef struct lio_s2m_config {
     int32_t device_id;       /* HIP device ordinal                                         */
     float   cell_size;       /* search radius covered by the grid neighbourhood, metres;
                                 0 = sqrt(max_sq_dist)*1.001.  Cell edge = cell_size/cell_div */
-    int32_t max_batch;       /* capacity: scans resident per batch (>= 1)                  */
-    int32_t max_scan_pts;    /* capacity: points per scan                                  */
+    int32_t max_batch;       /* hint: scans per batch (buffers grow on demand; may be 0)    */
+    int32_t max_scan_pts;    /* hint: points per scan (buffers grow on demand; may be 0)    */
     int32_t record_corr_iter;/* iteration whose correspondences are kept for
                                 lio_s2m_get_correspondences (-1 = none)                    */
     int32_t kernel_variant;  /* 0 = auto; >0 selects an association kernel (A/B testing)   */

@@ -406,14 +406,6 @@ LIO_DEV float lio_sqdist(float ax, float ay, float az, float bx, float by, float
     return r;
 }
 
-// Wave-wide sum with a fixed butterfly tree (deterministic).
-LIO_DEV double lio_wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
 // The serial Gauss-Newton step of one scan: LMOptimization MO:1702-1837 from
 // the reduced sums onward, plus the loop control of scan2MapOptimization
 // MO:1848-1859.  One lane; `ws` is LDS (or any) working storage.
