@@ -152,6 +152,31 @@ int  lio_s2m_set_degeneracy(lio_s2m_handle *h, int32_t scan, const float matP[36
 int  lio_s2m_get_correspondences(lio_s2m_handle *h, int32_t scan, uint8_t *flag,
                                  float *coeff4, int32_t *nn_idx5);
 
+/* ---- EXTENSION beyond this reference: point-to-line ("corner") residuals ------------------
+ * BASELINE.json's north_star names cornerOptimization, which this fork removed (its
+ * scan2MapOptimization MO:1839-1865 is surf-only).  These entry points
+ * add the cornerOptimization of upstream LIO-SAM (kdtreeCornerFromMap 5-NN, 3x3 covariance,
+ * cv::eigen, lambda0 > 3*lambda1, point-to-line distance) to the same Gauss-Newton loop:
+ * corner rows are appended to the surf rows exactly as upstream's combineOptimizationCoeffs
+ * does, and LMOptimization MO:1702-1837 is shared.  There is no reference oracle for them
+ * in /root/reference (parity unpinned: checked against oracle/lio_oracle.c lo_scan2map_cs
+ * only).  Without a corner batch every other entry point behaves exactly as before.
+ *
+ * set_corner_map          : kdtreeCornerFromMap->setInputCloud(laserCloudCornerFromMapDS)
+ * batch_upload_corners    : the scans' edge points (laserCloudCornerLastDS); call after
+ *                           lio_s2m_batch_upload with the same n_scans and before
+ *                           lio_s2m_batch_set_poses; n_pts[s] may be 0
+ * register_cs             : lio_s2m_register with both clouds
+ * get_corner_correspondences : as lio_s2m_get_correspondences, for the edge points */
+int  lio_s2m_set_corner_map(lio_s2m_handle *h, const void *pts, size_t n, size_t stride_bytes);
+int  lio_s2m_batch_upload_corners(lio_s2m_handle *h, int32_t n_scans, const void *const *scans,
+                                  const size_t *n_pts, size_t stride_bytes);
+int  lio_s2m_register_cs(lio_s2m_handle *h, const void *corner_scan, size_t n_corner,
+                         const void *surf_scan, size_t n_surf, size_t stride_bytes,
+                         float pose[6], lio_s2m_result *res);
+int  lio_s2m_get_corner_correspondences(lio_s2m_handle *h, int32_t scan, uint8_t *flag,
+                                        float *coeff4, int32_t *nn_idx5);
+
 int  lio_s2m_get_profile(lio_s2m_handle *h, lio_s2m_profile *out);
 /* Diagnostic (cfg.profile == 2): per-wave phase clock of the last GN launch,
  * n_blocks x 4 x 8 cycle counters; returns n_blocks.  Not for production. */

@@ -93,6 +93,8 @@ EXPORTS = [
     "lio_transform_update", "lio_deskew_default_config", "lio_imu_deskew_info", "lio_deskew",
     "lio_curvature", "lio_s2m_debug_stamps", "lio_s2m_batch_poll_active", "lio_voxel_grid", "lio_assemble_map", "lio_kf_store_create", "lio_kf_store_destroy", "lio_kf_store_add",
     "lio_kf_store_count", "lio_assemble_map_resident", "lio_s2m_set_scan_shard",
+    "lio_s2m_set_corner_map", "lio_s2m_batch_upload_corners", "lio_s2m_register_cs",
+    "lio_s2m_get_corner_correspondences",
 ]
 
 
@@ -124,6 +126,10 @@ def load_library():
     L.lio_s2m_set_degeneracy.argtypes = [vp, i32, C.POINTER(f32), i32]
     L.lio_s2m_get_correspondences.argtypes = [vp, i32, vp, vp, vp]
     L.lio_s2m_get_profile.argtypes = [vp, C.POINTER(S2MProfile)]
+    L.lio_s2m_set_corner_map.argtypes = [vp, vp, sz, sz]
+    L.lio_s2m_batch_upload_corners.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), sz]
+    L.lio_s2m_register_cs.argtypes = [vp, vp, sz, vp, sz, sz, C.POINTER(f32), C.POINTER(S2MResult)]
+    L.lio_s2m_get_corner_correspondences.argtypes = [vp, i32, vp, vp, vp]
     L.lio_s2m_set_stream.argtypes = [vp, vp]
     L.lio_s2m_set_global_grid.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
     L.lio_s2m_set_shard.argtypes = [vp, i32, i32, i32]
@@ -256,6 +262,43 @@ class ScanToMap:
         nn = np.full((n, 5), -1, np.int32)
         _check(self.lib.lio_s2m_get_correspondences(self.h, scan, flag.ctypes.data, coeff.ctypes.data,
                                                     nn.ctypes.data), "lio_s2m_get_correspondences")
+        return flag, coeff, nn
+
+    # ---- extension beyond this reference: point-to-line residuals (upstream LIO-SAM cornerOptimization) ----
+    def set_corner_map(self, map_pts):
+        a, stride = _as_points(np.asarray(map_pts, np.float32).reshape(-1, 3) if len(map_pts) == 0 else map_pts)
+        _check(self.lib.lio_s2m_set_corner_map(self.h, a.ctypes.data, len(a), stride), "lio_s2m_set_corner_map")
+
+    def batch_upload_corners(self, scans):
+        arrs = [_as_points(np.zeros((0, 3), np.float32) if len(s) == 0 else s) for s in scans]
+        n = len(arrs)
+        stride = {s for a, s in arrs if len(a)} or {12}
+        if len(stride) != 1:
+            raise ValueError("all scans of a batch must share one stride")
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data if len(a) else None for a, _ in arrs])
+        npts = (C.c_size_t * n)(*[len(a) for a, _ in arrs])
+        _check(self.lib.lio_s2m_batch_upload_corners(self.h, n, ptrs, npts, stride.pop()), "lio_s2m_batch_upload_corners")
+        self._ncorner = [len(a) for a, _ in arrs]
+
+    def scan2MapOptimizationCS(self, corner_pts, surf_pts, pose):
+        cpts, cstride = _as_points(corner_pts)
+        a, stride = _as_points(surf_pts)
+        if cstride != stride:
+            raise ValueError("corner and surf clouds must share one stride")
+        p = np.array(pose, np.float32).copy()
+        res = S2MResult()
+        rc = _check(self.lib.lio_s2m_register_cs(self.h, cpts.ctypes.data, len(cpts), a.ctypes.data, len(a), stride,
+                                                 _f32p(p), C.byref(res)), "lio_s2m_register_cs")
+        self._n_scans, self._npts, self._ncorner = 1, [len(a)], [len(cpts)]
+        return p, res, rc
+
+    def get_corner_correspondences(self, scan=0):
+        n = self._ncorner[scan]
+        flag = np.zeros(n, np.uint8)
+        coeff = np.zeros((n, 4), np.float32)
+        nn = np.full((n, 5), -1, np.int32)
+        _check(self.lib.lio_s2m_get_corner_correspondences(self.h, scan, flag.ctypes.data, coeff.ctypes.data,
+                                                           nn.ctypes.data), "lio_s2m_get_corner_correspondences")
         return flag, coeff, nn
 
     def profile(self):

@@ -189,6 +189,125 @@ LIO_DEV void lio_jacobian_row(const float tr[6], float px, float py, float pz,
     rhs = -cw;
 }
 
+__device__ static float lio_cv_hypot(float a, float b)
+{
+    a = fabsf(a); b = fabsf(b);
+    if (a > b) { b /= a; return a * sqrtf(1 + b * b); }
+    if (b > 0) { a /= b; return b * sqrtf(1 + a * a); }
+    return 0.0f;
+}
+
+// ------------------------------------------------- point-to-line residual (EXTENSION)
+// BASELINE.json's north_star names cornerOptimization; this reference has none, so
+// this follows upstream LIO-SAM's cornerOptimization and is checked against oracle/lio_oracle.c
+// lo_corner_point only ("parity unpinned": no reference fixture exists for it).
+//
+// cv::eigen on the symmetric 3x3 covariance: OpenCV's JacobiImpl_ specialised to n = 3 and held
+// entirely in registers.  Only the upper triangle (a01, a02, a12) is ever touched; of the pivot
+// trackers only indR[0] (r0) and indC[2] (c2) have a choice, indR[1] = 2 and indC[1] = 0 always.
+// They are refreshed exactly when the general algorithm refreshes them (rows/columns k and l of
+// the rotation just applied), including its stale-tracker behaviour.
+// Returns the two largest eigenvalues and the eigenvector (row 0 after the descending sort).
+LIO_DEV void lio_eigen3_sym(float a00, float a01, float a02, float a11, float a12, float a22,
+                            float& e0, float& e1, float axis[3])
+{
+    float w0 = a00, w1 = a11, w2 = a22;
+    float v00 = 1.0f, v01 = 0.0f, v02 = 0.0f, v10 = 0.0f, v11 = 1.0f, v12 = 0.0f, v20 = 0.0f, v21 = 0.0f, v22 = 1.0f;
+    int r0 = (fabsf(a01) < fabsf(a02)) ? 2 : 1;
+    int c2 = (fabsf(a02) < fabsf(a12)) ? 1 : 0;
+#pragma unroll 1
+    for (int iters = 0; iters < 3 * 3 * 30; ++iters) {
+        // pivot: rows first (k = 0 via indR[0], k = 1 via indR[1] = 2), then columns 1 and 2
+        int pair = (r0 == 1) ? 0 : 1;                       // (0,1) -> 0, (0,2) -> 1, (1,2) -> 2
+        float mv = fabsf(r0 == 1 ? a01 : a02);
+        if (mv < fabsf(a12)) { mv = fabsf(a12); pair = 2; }
+        if (mv < fabsf(a01)) { mv = fabsf(a01); pair = 0; }
+        const float vc = (c2 == 0) ? a02 : a12;
+        if (mv < fabsf(vc)) { mv = fabsf(vc); pair = (c2 == 0) ? 1 : 2; }
+        const float p = pair == 0 ? a01 : (pair == 1 ? a02 : a12);
+        if (fabsf(p) <= FLT_EPSILON) break;
+        const float wk = pair == 2 ? w1 : w0, wl = pair == 0 ? w1 : w2;
+        const float y = (wl - wk) * 0.5f;                    // == (float)((W[l] - W[k]) * 0.5)
+        float t = fabsf(y) + lio_cv_hypot(p, y);
+        float s = lio_cv_hypot(p, t);
+        const float c = t / s;
+        s = p / s; t = (p / t) * p;
+        if (y < 0) { s = -s; t = -t; }
+        float a0, b0;
+#define LIO_ROT(u0, u1) do { a0 = (u0); b0 = (u1); (u0) = a0 * c - b0 * s; (u1) = a0 * s + b0 * c; } while (0)
+        if (pair == 0) {            // (k,l) = (0,1), third index 2 > l: rotate (A[k][2], A[l][2])
+            a01 = 0.0f; w0 -= t; w1 += t;
+            LIO_ROT(a02, a12);
+            LIO_ROT(v00, v10); LIO_ROT(v01, v11); LIO_ROT(v02, v12);
+            r0 = (fabsf(a01) < fabsf(a02)) ? 2 : 1;
+        } else if (pair == 1) {     // (0,2), third index 1 in between: rotate (A[k][1], A[1][l])
+            a02 = 0.0f; w0 -= t; w2 += t;
+            LIO_ROT(a01, a12);
+            LIO_ROT(v00, v20); LIO_ROT(v01, v21); LIO_ROT(v02, v22);
+            r0 = (fabsf(a01) < fabsf(a02)) ? 2 : 1;
+            c2 = (fabsf(a02) < fabsf(a12)) ? 1 : 0;
+        } else {                    // (1,2), third index 0 < k: rotate (A[0][k], A[0][l])
+            a12 = 0.0f; w1 -= t; w2 += t;
+            LIO_ROT(a01, a02);
+            LIO_ROT(v10, v20); LIO_ROT(v11, v21); LIO_ROT(v12, v22);
+            c2 = (fabsf(a02) < fabsf(a12)) ? 1 : 0;
+        }
+#undef LIO_ROT
+    }
+    // descending selection sort (first maximum wins), eigenvectors are rows
+    int m = 0;
+    if (w0 < w1) m = 1;
+    if ((m == 0 ? w0 : w1) < w2) m = 2;
+    float t0;
+#define LIO_SWAP(x, y) do { t0 = (x); (x) = (y); (y) = t0; } while (0)
+    if (m == 1) { LIO_SWAP(w0, w1); LIO_SWAP(v00, v10); LIO_SWAP(v01, v11); LIO_SWAP(v02, v12); }
+    if (m == 2) { LIO_SWAP(w0, w2); LIO_SWAP(v00, v20); LIO_SWAP(v01, v21); LIO_SWAP(v02, v22); }
+    if (w1 < w2) LIO_SWAP(w1, w2);
+#undef LIO_SWAP
+    e0 = w0; e1 = w1;
+    axis[0] = v00; axis[1] = v01; axis[2] = v02;
+}
+
+// Upstream LIO-SAM cornerOptimization, after the 5-NN gate: m = the five neighbours (caller's map
+// order), q = the transformed scan point.  Writes coeff = s * (la, lb, lc, ld2); returns s > min_s.
+LIO_DEV bool lio_corner_assoc(const float m[5][3], float x0, float y0, float z0, double weight, double min_s,
+                              float& ox, float& oy, float& oz, float& ow)
+{
+    float cx = 0, cy = 0, cz = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { cx += m[j][0]; cy += m[j][1]; cz += m[j][2]; }
+    cx /= 5; cy /= 5; cz /= 5;
+    float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float ax = m[j][0] - cx, ay = m[j][1] - cy, az = m[j][2] - cz;
+        a11 += ax * ax; a12 += ax * ay; a13 += ax * az;
+        a22 += ay * ay; a23 += ay * az;
+        a33 += az * az;
+    }
+    a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
+    float e0, e1, v[3];
+    lio_eigen3_sym(a11, a12, a13, a22, a23, a33, e0, e1, v);
+    ox = oy = oz = ow = 0.0f;
+    if (!(e0 > 3 * e1)) return false;
+    const float x1 = (float)((double)cx + 0.1 * (double)v[0]), y1 = (float)((double)cy + 0.1 * (double)v[1]),
+                z1 = (float)((double)cz + 0.1 * (double)v[2]);
+    const float x2 = (float)((double)cx - 0.1 * (double)v[0]), y2 = (float)((double)cy - 0.1 * (double)v[1]),
+                z2 = (float)((double)cz - 0.1 * (double)v[2]);
+    const float m1 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
+    const float m2 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
+    const float m3 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
+    const float a012 = sqrtf(m1 * m1 + m2 * m2 + m3 * m3);
+    const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+    const float la = ((y1 - y2) * m1 + (z1 - z2) * m2) / a012 / l12;
+    const float lb = -((x1 - x2) * m1 - (z1 - z2) * m3) / a012 / l12;
+    const float lc = -((x1 - x2) * m2 + (y1 - y2) * m3) / a012 / l12;
+    const float ld2 = a012 / l12;
+    const float s = (float)(1 - weight * (double)fabsf(ld2));
+    ox = s * la; oy = s * lb; oz = s * lc; ow = s * ld2;
+    return (double)s > min_s;
+}
+
 // ------------------------------------------------- 6x6 normal-equation step
 // Executed by ONE lane per scan per iteration (the serial tail of the GN
 // step).  All working storage is a caller-provided LDS workspace so that the
@@ -241,13 +360,6 @@ __device__ static int lio_solve6_qr(float* A, float* b, float* vl, float* hf)
     return 1;
 }
 
-__device__ static float lio_cv_hypot(float a, float b)
-{
-    a = fabsf(a); b = fabsf(b);
-    if (a > b) { b /= a; return a * sqrtf(1 + b * b); }
-    if (b > 0) { a /= b; return b * sqrtf(1 + a * a); }
-    return 0.0f;
-}
 
 // cv::eigen(matAtA, matE, matV), MO:1792 (OpenCV JacobiImpl_: largest
 // off-diagonal pivot tracked per row/column; eigenvalues sorted descending,

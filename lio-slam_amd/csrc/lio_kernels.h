@@ -40,7 +40,7 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
 int  lio_scan_tiles(int n_cells);
 void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c,
                            int* n_active, hipStream_t s);
-void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s);
+void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s, bool corner = false);
 void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
                       int* n_active, hipStream_t s);
 void lio_launch_scan_tile_sort(const void* stage, size_t stride, int total_pts,

@@ -643,7 +643,10 @@ LIO_DEV void lio_arrive_and_finish(const LioIterParams& P, const LioBlockDesc& b
 // through LDS once (coalesced 16-byte loads) and every lane scans its
 // candidates from LDS.  Regions that do not fit fall back to the global form;
 // both forms visit the same candidate set, so results are identical.
-template <int PPT, bool STAGE>
+// CORNER (extension): the same workgroup structure over the scan's EDGE points against
+// the corner map with the point-to-line association of upstream LIO-SAM; its rows join the same
+// per-scan sums (combineOptimizationCoeffs) through the partials of chunks n_surf_chunks.. .
+template <int PPT, bool STAGE, bool CORNER>
 __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIterParams P)
 {
     __shared__ __attribute__((aligned(16))) float s_rows[LIO_BLOCK][8];   // [arz ary arx cx cy cz | -cw | accepted]
@@ -679,8 +682,8 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
     for (int k = 0; k < 12; ++k) T[k] = st->T[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) tr[k] = st->trig[k];
-    const int n_pts = st->n_pts;
-    const int base = st->offset;
+    const int n_pts = CORNER ? st->c_n_pts : st->n_pts;
+    const int base = CORNER ? st->c_offset : st->offset;
     const bool record = (P.rec_flag != nullptr) && (st->iter == P.c.record_iter);
     const LioGrid g = P.grid;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -841,24 +844,28 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
                 m[j][1] = a[j][1] = mp.y;
                 m[j][2] = a[j][2] = mp.z;
             }
-            float X0[3];
-            lio_plane_qr5x3(a, X0);                                  // MO:1648
-            float pa = X0[0], pb = X0[1], pc = X0[2], pd = 1;         // MO:1650-1653
-            const float ps = sqrtf(pa * pa + pb * pb + pc * pc);      // MO:1655
-            pa /= ps; pb /= ps; pc /= ps; pd /= ps;                   // MO:1656
-            bool planeValid = true;                                   // MO:1658-1666
+            if (CORNER) {
+                accept = lio_corner_assoc(m, qx[pp], qy[pp], qz[pp], P.c.weight, P.c.min_s, cxx, cyy, czz, cww);
+            } else {
+                float X0[3];
+                lio_plane_qr5x3(a, X0);                                  // MO:1648
+                float pa = X0[0], pb = X0[1], pc = X0[2], pd = 1;         // MO:1650-1653
+                const float ps = sqrtf(pa * pa + pb * pb + pc * pc);      // MO:1655
+                pa /= ps; pb /= ps; pc /= ps; pd /= ps;                   // MO:1656
+                bool planeValid = true;                                   // MO:1658-1666
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const float v = fabsf(pa * m[j][0] + pb * m[j][1] + pc * m[j][2] + pd);
-                if ((double)v > P.c.plane_tol) planeValid = false;
-            }
-            if (planeValid) {
-                const float pd2 = pa * qx[pp] + pb * qy[pp] + pc * qz[pp] + pd;   // MO:1669
-                const float r2 = px[pp] * px[pp] + py[pp] * py[pp] + pz[pp] * pz[pp];
-                // MO:1671-1672 (product, quotient and difference in double)
-                const float s = (float)(1 - P.c.weight * (double)fabsf(pd2) / (double)sqrtf(sqrtf(r2)));
-                cxx = s * pa; cyy = s * pb; czz = s * pc; cww = s * pd2;   // MO:1674-1677
-                accept = (double)s > P.c.min_s;                       // MO:1679
+                for (int j = 0; j < 5; ++j) {
+                    const float v = fabsf(pa * m[j][0] + pb * m[j][1] + pc * m[j][2] + pd);
+                    if ((double)v > P.c.plane_tol) planeValid = false;
+                }
+                if (planeValid) {
+                    const float pd2 = pa * qx[pp] + pb * qy[pp] + pc * qz[pp] + pd;   // MO:1669
+                    const float r2 = px[pp] * px[pp] + py[pp] * py[pp] + pz[pp] * pz[pp];
+                    // MO:1671-1672 (product, quotient and difference in double)
+                    const float s = (float)(1 - P.c.weight * (double)fabsf(pd2) / (double)sqrtf(sqrtf(r2)));
+                    cxx = s * pa; cyy = s * pb; czz = s * pc; cww = s * pd2;   // MO:1674-1677
+                    accept = (double)s > P.c.min_s;                       // MO:1679
+                }
             }
         }
         if (record && inr[pp]) {
@@ -972,21 +979,25 @@ void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, co
     hipLaunchKernelGGL(k_s2m_init_state, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, poses, c, n_active);
 }
 
-void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s)
+void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s, bool corner)
 {
     if (n_blocks <= 0) return;
     const dim3 gr(n_blocks), bl(LIO_BLOCK);
+    if (corner) {                      // extension: edge points, always one point per thread from global memory
+        hipLaunchKernelGGL((k_s2m_iterate<1, false, true>), gr, bl, 0, s, P);
+        return;
+    }
     if (stage) {
         switch (ppt) {
-        case 1: hipLaunchKernelGGL((k_s2m_iterate<1, true>), gr, bl, 0, s, P); break;
-        case 2: hipLaunchKernelGGL((k_s2m_iterate<2, true>), gr, bl, 0, s, P); break;
-        default: hipLaunchKernelGGL((k_s2m_iterate<4, true>), gr, bl, 0, s, P); break;
+        case 1: hipLaunchKernelGGL((k_s2m_iterate<1, true, false>), gr, bl, 0, s, P); break;
+        case 2: hipLaunchKernelGGL((k_s2m_iterate<2, true, false>), gr, bl, 0, s, P); break;
+        default: hipLaunchKernelGGL((k_s2m_iterate<4, true, false>), gr, bl, 0, s, P); break;
         }
     } else {
         switch (ppt) {
-        case 1: hipLaunchKernelGGL((k_s2m_iterate<1, false>), gr, bl, 0, s, P); break;
-        case 2: hipLaunchKernelGGL((k_s2m_iterate<2, false>), gr, bl, 0, s, P); break;
-        default: hipLaunchKernelGGL((k_s2m_iterate<4, false>), gr, bl, 0, s, P); break;
+        case 1: hipLaunchKernelGGL((k_s2m_iterate<1, false, false>), gr, bl, 0, s, P); break;
+        case 2: hipLaunchKernelGGL((k_s2m_iterate<2, false, false>), gr, bl, 0, s, P); break;
+        default: hipLaunchKernelGGL((k_s2m_iterate<4, false, false>), gr, bl, 0, s, P); break;
         }
     }
 }

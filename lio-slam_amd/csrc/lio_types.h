@@ -46,6 +46,8 @@ struct LioScanState {
     float trig[6];
     int32_t n_pts;
     int32_t offset;          // first point of this scan in the batch SoA
+    int32_t c_n_pts;         // EXTENSION (corner residuals): the scan's edge points, in the corner batch SoA
+    int32_t c_offset;
     int32_t iter;            // iterations executed
     int32_t done;
     int32_t converged;

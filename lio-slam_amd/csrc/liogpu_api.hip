@@ -115,6 +115,14 @@ struct lio_s2m_handle {
     bool has_global = false;
     int block_rank = 0, block_world = 1;   // scan-range sharding
 
+    // EXTENSION: point-to-line residuals.  `corner` is a child handle that owns the corner
+    // map (its grid and neighbourhood rows) and the batch of edge points; its association launch writes
+    // into THIS handle's per-scan partial sums and state.
+    lio_s2m_handle* corner = nullptr;
+    bool corner_active = false;       // a corner batch matching the current surf batch is resident
+    LioIterParams graph_params_c;
+    int graph_blocks_c = 0;
+
     // profiling
     hipEvent_t ev_beg[LIO_MAX_ITERS], ev_end[LIO_MAX_ITERS], ev_chk[LIO_MAX_ITERS];
     hipEvent_t ev_map[2];
@@ -213,6 +221,7 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device_id);
     (void)hipStreamSynchronize(h->stream);
+    if (h->corner) { lio_s2m_destroy(h->corner); h->corner = nullptr; }
     void* ptrs[] = { h->d_mx, h->d_my, h->d_mz, h->d_map4, h->d_sorted, h->d_cell_of, h->d_cell_count,
                      h->d_cell_start, h->d_tile_sums, h->d_bbox, h->d_stage, h->d_sx, h->d_sy, h->d_sz,
                      h->d_state, h->d_poses, h->d_blocks, h->d_partials, h->d_arrive, h->d_rec_flag,
@@ -241,6 +250,7 @@ extern "C" int lio_s2m_set_stream(lio_s2m_handle* h, void* hip_stream)
     h->stream = (hipStream_t)hip_stream;
     h->own_stream = false;
     h->graph_dirty = true;
+    if (h->corner) return lio_s2m_set_stream(h->corner, hip_stream);
     return LIO_OK;
 }
 
@@ -443,6 +453,8 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         if ((size_t)s >= old_scans) memset(&st, 0, sizeof(st));   // keep matP / is_degenerate of live slots
         st.n_pts = (int)n_pts[s];
         st.offset = (int)off;
+        st.c_n_pts = 0;                // a corner batch has to be uploaded again after every surf batch
+        st.c_offset = 0;
         st.done = 1;
         const int nb = (int)((n_pts[s] + per_blk - 1) / per_blk);
         // scan-range sharding ("replicate the map, shard the scan"): this rank takes one
@@ -545,7 +557,88 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     h->poses_set = false;
     h->ran = false;
     h->graph_dirty = true;
+    h->corner_active = false;
     return LIO_OK;
+}
+
+// ------------------------------------------------- corner residuals (extension)
+extern "C" int lio_s2m_set_corner_map(lio_s2m_handle* h, const void* pts, size_t n, size_t stride)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();
+    if (!h->corner) {
+        lio_s2m_config cc = h->cfg;
+        cc.kernel_variant = 1;         // edge sets are small: one point per thread, candidates from global memory
+        cc.use_lds = 0;
+        cc.profile = 0;
+        cc.use_graph = 0;
+        int rc = lio_s2m_create(&cc, &h->corner);
+        if (rc != LIO_OK) return rc;
+        if ((rc = lio_s2m_set_stream(h->corner, h->stream)) != LIO_OK) return rc;
+    }
+    h->corner_active = false;
+    h->graph_dirty = true;
+    return lio_s2m_set_map(h->corner, pts, n, stride);
+}
+
+extern "C" int lio_s2m_batch_upload_corners(lio_s2m_handle* h, int32_t n_scans, const void* const* scans,
+                                            const size_t* n_pts, size_t stride)
+{
+    if (!h || !scans || !n_pts) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (!h->corner || !h->corner->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_corner_map has not been called");
+    if (h->n_scans < 1 || n_scans != h->n_scans)
+        return lio_fail(LIO_ERR_ARG, "upload the surf batch first; the corner batch must have the same number of scans");
+    lio_s2m_handle* ch = h->corner;
+    ch->block_rank = h->block_rank;
+    ch->block_world = h->block_world;
+    ch->defer_sync = h->defer_sync;
+    int rc = lio_s2m_batch_upload(ch, n_scans, scans, n_pts, stride);
+    ch->defer_sync = false;
+    if (rc != LIO_OK) return rc;
+    // One arrival counter and one partial-sum table per scan serve both launches: the scan's corner
+    // chunks are numbered after its surf chunks (combineOptimizationCoeffs appends one list to the other).
+    int max_blk = 1;
+    for (LioBlockDesc& b : h->v_blocks) {
+        const int ns = h->v_first_orig[b.scan + 1] - h->v_first_orig[b.scan];
+        const int nc = ch->v_first_orig[b.scan + 1] - ch->v_first_orig[b.scan];
+        b.n_blk = ns + nc;
+        if (b.n_blk > max_blk) max_blk = b.n_blk;
+    }
+    for (LioBlockDesc& b : ch->v_blocks) {
+        const int ns = h->v_first_orig[b.scan + 1] - h->v_first_orig[b.scan];
+        const int nc = ch->v_first_orig[b.scan + 1] - ch->v_first_orig[b.scan];
+        b.blk += ns;
+        b.n_blk = ns + nc;
+        if (b.n_blk > max_blk) max_blk = b.n_blk;
+    }
+    h->max_blk = max_blk;
+    HIPCHK(lio_grow(&h->d_partials, &h->cap_partials, (size_t)n_scans * max_blk * LIO_SUMS));
+    if (!h->v_blocks.empty())
+        HIPCHK(hipMemcpyAsync(h->d_blocks, h->v_blocks.data(), h->v_blocks.size() * sizeof(LioBlockDesc),
+                              hipMemcpyHostToDevice, h->stream));
+    if (!ch->v_blocks.empty())
+        HIPCHK(hipMemcpyAsync(ch->d_blocks, ch->v_blocks.data(), ch->v_blocks.size() * sizeof(LioBlockDesc),
+                              hipMemcpyHostToDevice, h->stream));
+    for (int s = 0; s < n_scans; ++s) {
+        h->h_state[s].c_n_pts = ch->h_state[s].n_pts;
+        h->h_state[s].c_offset = ch->h_state[s].offset;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_state, h->h_state.data(), (size_t)n_scans * sizeof(LioScanState),
+                          hipMemcpyHostToDevice, h->stream));
+    if (!h->defer_sync) HIPCHK(hipStreamSynchronize(h->stream));
+    h->corner_active = true;
+    h->poses_set = false;             // (the workgroup list was rewritten: batch_set_poses re-orders it)
+    h->graph_dirty = true;
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_get_corner_correspondences(lio_s2m_handle* h, int32_t scan, uint8_t* flag,
+                                                  float* coeff4, int32_t* nn_idx5)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    if (!h->corner || !h->corner_active) return lio_fail(LIO_ERR_ARG, "no corner batch is resident");
+    return lio_s2m_get_correspondences(h->corner, scan, flag, coeff4, nn_idx5);
 }
 
 extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
@@ -630,6 +723,29 @@ static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_ou
     P.stamps = (h->cfg.profile == 2) ? h->d_stamps : nullptr;
 }
 
+// Arguments of the corner launch: the child's map, grid, edge points and workgroup list; everything
+// that is per scan (state, partial sums, arrival counters, active count) is the parent's.
+static void lio_fill_params_corner(lio_s2m_handle* h, LioIterParams& Pc, double* sums_out)
+{
+    lio_fill_params(h->corner, Pc, sums_out);
+    Pc.shard = h->shard;
+    Pc.state = h->d_state;
+    Pc.partials = h->d_partials;
+    Pc.arrive = h->d_arrive;
+    Pc.max_blk = h->max_blk;
+    Pc.n_active = h->d_active;
+    Pc.stamps = nullptr;
+}
+
+// One Gauss-Newton iteration of the batch: cornerOptimization (if a corner batch is resident), then
+// surfOptimization MO:1618-1687; the workgroup that arrives last on a scan's counter runs
+// LMOptimization MO:1702-1837 for it.
+static void lio_launch_gn(lio_s2m_handle* h, const LioIterParams& P, const LioIterParams* Pc)
+{
+    if (Pc) lio_launch_iterate(*Pc, h->corner->n_blocks, 1, false, h->stream, true);
+    lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
+}
+
 extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
 {
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
@@ -648,20 +764,24 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
 // (Re)capture `chunk` consecutive GN-iteration launches into a hipGraph.  Every launch has the
 // same arguments -- all per-iteration state lives in device memory -- so one executable graph
 // serves the whole loop; scans that are done turn their workgroups into immediate exits.
-static int lio_graph_prepare(lio_s2m_handle* h, const LioIterParams& P, int chunk)
+static int lio_graph_prepare(lio_s2m_handle* h, const LioIterParams& P, const LioIterParams* Pc, int chunk)
 {
     // the cached graph stays valid as long as the kernel arguments and the launch geometry are the same
+    const int nbc = Pc ? h->corner->n_blocks : -1;
     if (h->graph_exec && h->graph_chunk == chunk && h->graph_blocks == h->n_blocks && h->graph_ppt == h->ppt &&
-        memcmp(&h->graph_params, &P, sizeof(P)) == 0)
+        memcmp(&h->graph_params, &P, sizeof(P)) == 0 && h->graph_blocks_c == nbc &&
+        (!Pc || memcmp(&h->graph_params_c, Pc, sizeof(P)) == 0))
         return LIO_OK;
     if (h->graph_exec) { HIPCHK(hipGraphExecDestroy(h->graph_exec)); h->graph_exec = nullptr; }
     if (h->graph) { HIPCHK(hipGraphDestroy(h->graph)); h->graph = nullptr; }
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < chunk; ++i) lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
+    for (int i = 0; i < chunk; ++i) lio_launch_gn(h, P, Pc);
     HIPCHK(hipStreamEndCapture(h->stream, &h->graph));
     HIPCHK(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
     h->graph_chunk = chunk; h->graph_blocks = h->n_blocks; h->graph_ppt = h->ppt;
     memcpy(&h->graph_params, &P, sizeof(P));
+    h->graph_blocks_c = nbc;
+    if (Pc) memcpy(&h->graph_params_c, Pc, sizeof(P));
     h->graph_dirty = false;
     return LIO_OK;
 }
@@ -673,6 +793,10 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
     LioIterParams P;
     memset(&P, 0, sizeof(P));          // (padding bytes take part in the graph-cache comparison)
     lio_fill_params(h, P, nullptr);
+    LioIterParams Pcs;
+    memset(&Pcs, 0, sizeof(Pcs));
+    const LioIterParams* Pc = nullptr;
+    if (h->corner_active && h->corner->n_blocks > 0) { lio_fill_params_corner(h, Pcs, nullptr); Pc = &Pcs; }
     const bool prof = h->cfg.profile != 0;
     // The GN loop (MO:1848-1859) runs ahead of the device by `lookahead` launches: after every
     // launch (or graph replay) the count of still-iterating scans is copied to pinned memory;
@@ -686,7 +810,7 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
     if (graph) {
         chunk = h->cfg.graph_iters > 0 ? h->cfg.graph_iters : 4;
         if (chunk > h->cfg.max_iters) chunk = h->cfg.max_iters;
-        if ((rc = lio_graph_prepare(h, P, chunk)) != LIO_OK) return rc;
+        if ((rc = lio_graph_prepare(h, P, Pc, chunk)) != LIO_OK) return rc;
         if (h->cfg.lookahead < 0) look = 0;              // a chunk already is a run-ahead of `chunk` launches
     }
     const int n_units = (h->cfg.max_iters + chunk - 1) / chunk;
@@ -699,7 +823,7 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
         }
         if (prof) HIPCHK(hipEventRecord(h->ev_beg[u], h->stream));
         if (graph) HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
-        else lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
+        else lio_launch_gn(h, P, Pc);
         if (prof) HIPCHK(hipEventRecord(h->ev_end[u], h->stream));
         HIPCHK(hipMemcpyAsync(&h->h_active[u], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipEventRecord(h->ev_chk[u], h->stream));
@@ -724,7 +848,10 @@ extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
     const int it = h->launches_this_run;
     const bool prof = h->cfg.profile != 0 && it < LIO_MAX_ITERS;
     if (prof) HIPCHK(hipEventRecord(h->ev_beg[it], h->stream));
-    lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
+    LioIterParams Pcs;
+    const bool with_corners = h->corner_active && h->corner->n_blocks > 0;
+    if (with_corners) lio_fill_params_corner(h, Pcs, d_sums);
+    lio_launch_gn(h, P, with_corners ? &Pcs : nullptr);
     if (prof) HIPCHK(hipEventRecord(h->ev_end[it], h->stream));
     h->launches_this_run++;
     h->units_this_run = h->launches_this_run;
@@ -795,7 +922,7 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
         const LioScanState& st = h->h_state[s];
         if (poses) memcpy(poses + (size_t)s * 6, st.pose, sizeof(float) * 6);
         // a "< 50 correspondences" scan was fast-forwarded: it did its work once
-        pit += (int64_t)st.n_pts * (st.status == 2 ? 1 : st.iter) * (st.status == 1 ? 0 : 1);
+        pit += (int64_t)(st.n_pts + st.c_n_pts) * (st.status == 2 ? 1 : st.iter) * (st.status == 1 ? 0 : 1);
         if (results) {
             lio_s2m_result& r = results[s];
             memset(&r, 0, sizeof(r));
@@ -847,6 +974,28 @@ extern "C" int lio_s2m_register(lio_s2m_handle* h, const void* scan, size_t n, s
     // (the caller's buffers stay valid for the whole call)
     h->defer_sync = true;
     int rc = lio_s2m_batch_upload(h, 1, scans, np, stride);
+    if (rc == LIO_OK) rc = lio_s2m_batch_set_poses(h, pose);
+    if (rc == LIO_OK) rc = lio_s2m_batch_run(h);
+    h->defer_sync = false;
+    if (rc != LIO_OK) { (void)hipStreamSynchronize(h->stream); return rc; }
+    lio_s2m_result local;
+    if ((rc = lio_s2m_batch_results(h, pose, res ? res : &local)) != LIO_OK) return rc;
+    return (res ? res : &local)->status;
+}
+
+extern "C" int lio_s2m_register_cs(lio_s2m_handle* h, const void* corner_scan, size_t n_corner,
+                                   const void* surf_scan, size_t n_surf, size_t stride,
+                                   float pose[6], lio_s2m_result* res)
+{
+    if (!h || !pose) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (!h->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
+    if (n_corner && (!h->corner || !h->corner->has_map)) return lio_fail(LIO_ERR_NO_MAP, "set_corner_map has not been called");
+    const void* scans[1] = { surf_scan };
+    const void* cscans[1] = { corner_scan };
+    size_t np[1] = { n_surf }, ncp[1] = { n_corner };
+    h->defer_sync = true;
+    int rc = lio_s2m_batch_upload(h, 1, scans, np, stride);
+    if (rc == LIO_OK && n_corner) rc = lio_s2m_batch_upload_corners(h, 1, cscans, ncp, stride);
     if (rc == LIO_OK) rc = lio_s2m_batch_set_poses(h, pose);
     if (rc == LIO_OK) rc = lio_s2m_batch_run(h);
     h->defer_sync = false;

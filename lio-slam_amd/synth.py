@@ -280,3 +280,50 @@ def make_case(sensor="vlp16", n_keyframes=10, seed=BASE_SEED, kind="street", n_q
         scan, init = make_query(boxes, tp, sensor, seed=seed + 5000 + q, device=device)
         queries.append({"scan": scan, "pose_true": tp.astype(np.float32), "pose_init": init})
     return {"map": map_xyz, "queries": queries, "boxes": boxes, "kf_poses": kfs, "keyframes": kept}
+
+
+# ------------------------------------------------------------- edge features
+# Extension data: this reference has no corner features; for the point-to-line
+# residuals of upstream LIO-SAM the generator samples the vertical edges of the scene boxes the way
+# a spinning lidar sees them -- one return per ring where the ring's cone meets the edge.
+def cast_edges(boxes, pose, sensor="vlp16", seed=0, noise=0.01, max_range=40.0):
+    """Edge returns of one sweep in the LIDAR frame, float32 [n,3] (occlusion is ignored)."""
+    n_rings, _, e0, e1 = SENSORS[sensor] if isinstance(sensor, str) else sensor
+    rng = np.random.Generator(np.random.MT19937(seed + 41))
+    pose = np.asarray(pose, np.float64)
+    b = np.asarray(boxes, np.float64)
+    ex = np.concatenate([b[:, 0], b[:, 0], b[:, 3], b[:, 3]])
+    ey = np.concatenate([b[:, 1], b[:, 4], b[:, 1], b[:, 4]])
+    ez0 = np.tile(b[:, 2], 4)
+    ez1 = np.tile(b[:, 5], 4)
+    d = np.hypot(ex - pose[3], ey - pose[4])
+    keep = (d > 1.0) & (d < max_range)
+    ex, ey, ez0, ez1, d = ex[keep], ey[keep], ez0[keep], ez1[keep], d[keep]
+    elev = np.radians(np.linspace(e0, e1, n_rings))
+    z = pose[5] + d[:, None] * np.tan(elev)[None, :]
+    ok = (z > ez0[:, None] + 0.05) & (z < ez1[:, None] - 0.05)
+    wx = np.broadcast_to(ex[:, None], z.shape)[ok]
+    wy = np.broadcast_to(ey[:, None], z.shape)[ok]
+    world = np.stack([wx, wy, z[ok]], 1)
+    T = pose_matrix(pose)
+    local = (world - T[:3, 3]) @ T[:3, :3]                    # R^T (p - t)
+    local += rng.normal(0, noise, local.shape)
+    return local.astype(np.float32)
+
+
+def add_corners(case, sensor="vlp16", seed=BASE_SEED, map_leaf=0.2,
+                pose_noise=(0.01, math.radians(0.05))):
+    """Adds "corner_map" and per-query "corners" to a make_case() dict (in place; returns it)."""
+    rng = np.random.Generator(np.random.MT19937(seed + 43))
+    clouds = []
+    for k, pose in enumerate(case["kf_poses"]):
+        loc = cast_edges(case["boxes"], pose, sensor, seed=seed + 2000 + k)
+        noisy = np.array(pose, np.float64)
+        noisy[3:6] += rng.normal(0, pose_noise[0], 3)
+        noisy[0:3] += rng.normal(0, pose_noise[1], 3)
+        clouds.append(transform_points(loc, noisy))
+    allc = np.concatenate(clouds, 0) if clouds else np.zeros((0, 3), np.float32)
+    case["corner_map"] = voxel_downsample(allc, map_leaf) if len(allc) else allc
+    for q, qu in enumerate(case["queries"]):
+        qu["corners"] = cast_edges(case["boxes"], qu["pose_true"], sensor, seed=seed + 7000 + q)
+    return case

@@ -1147,3 +1147,227 @@ int lo_voxel_grid(const float *in_xyzi, size_t n, float leaf, float *out_xyzi, s
     *n_out = o;
     return 0;
 }
+
+/* =========================================================================
+ * EXTENSION BEYOND THE REFERENCE -- point-to-line ("corner") residuals.
+ *
+ * BASELINE.json's north_star names `cornerOptimization`, but this reference (a liorf fork) has
+ * none: its scan-to-map loop is surf-only.  What follows restates the
+ * cornerOptimization of upstream LIO-SAM (TixiaoShan/LIO-SAM mapOptmization.cpp, the code liorf
+ * was forked from; not present under /root/reference), so that the kernels can be exercised with
+ * both residual types.  There is NO reference oracle for it in this tree: parity unpinned,
+ * self-consistency tests only.  With no corner input everything above is unchanged.
+ *
+ * upstream: 5-NN in the corner map, gate sqDis[4] < 1.0, centroid + covariance of the five
+ * neighbours (each /5), cv::eigen 3x3, line iff lambda0 > 3*lambda1, two points +-0.1 along the
+ * principal axis, point-to-line distance ld2 = a012 / l12 and its gradient (la, lb, lc),
+ * s = 1 - 0.9*fabs(ld2), coeff = s*(la, lb, lc, ld2), accept iff s > 0.1.
+ * ========================================================================= */
+
+/* cv::eigen for a symmetric 3x3 CV_32F matrix: the same JacobiImpl_ as lo_eigen6_sym with n = 3 */
+void lo_eigen3_sym(const float A_in[9], float W[3], float V[9])
+{
+    enum { N = 3 };
+    float A[N][N];
+    int indR[N], indC[N];
+    const float eps = FLT_EPSILON;
+    int i, j, k, m;
+    float mv;
+    for (i = 0; i < N; ++i) for (j = 0; j < N; ++j) { A[i][j] = A_in[i * N + j]; V[i * N + j] = (i == j) ? 1.0f : 0.0f; }
+    for (k = 0; k < N; ++k) {
+        W[k] = A[k][k];
+        if (k < N - 1) {
+            for (m = k + 1, mv = fabsf(A[k][m]), i = k + 2; i < N; ++i) {
+                float val = fabsf(A[k][i]);
+                if (mv < val) { mv = val; m = i; }
+            }
+            indR[k] = m;
+        }
+        if (k > 0) {
+            for (m = 0, mv = fabsf(A[0][k]), i = 1; i < k; ++i) {
+                float val = fabsf(A[i][k]);
+                if (mv < val) { mv = val; m = i; }
+            }
+            indC[k] = m;
+        }
+    }
+    for (int iters = 0; iters < N * N * 30; ++iters) {
+        for (k = 0, mv = fabsf(A[0][indR[0]]), i = 1; i < N - 1; ++i) {
+            float val = fabsf(A[i][indR[i]]);
+            if (mv < val) { mv = val; k = i; }
+        }
+        int l = indR[k];
+        for (i = 1; i < N; ++i) {
+            float val = fabsf(A[indC[i]][i]);
+            if (mv < val) { mv = val; k = indC[i]; l = i; }
+        }
+        float p = A[k][l];
+        if (fabsf(p) <= eps) break;
+        float y = (float)((W[l] - W[k]) * 0.5);
+        float t = fabsf(y) + lo_cv_hypot(p, y);
+        float s = lo_cv_hypot(p, t);
+        float c = t / s;
+        s = p / s; t = (p / t) * p;
+        if (y < 0) { s = -s; t = -t; }
+        A[k][l] = 0;
+        W[k] -= t;
+        W[l] += t;
+        float a0, b0;
+#define LO_ROT(v0, v1) do { a0 = (v0); b0 = (v1); (v0) = a0 * c - b0 * s; (v1) = a0 * s + b0 * c; } while (0)
+        for (i = 0; i < k; ++i)     LO_ROT(A[i][k], A[i][l]);
+        for (i = k + 1; i < l; ++i) LO_ROT(A[k][i], A[i][l]);
+        for (i = l + 1; i < N; ++i) LO_ROT(A[k][i], A[l][i]);
+        for (i = 0; i < N; ++i)     LO_ROT(V[k * N + i], V[l * N + i]);
+#undef LO_ROT
+        for (j = 0; j < 2; ++j) {
+            int idx = j == 0 ? k : l;
+            if (idx < N - 1) {
+                for (m = idx + 1, mv = fabsf(A[idx][m]), i = idx + 2; i < N; ++i) {
+                    float val = fabsf(A[idx][i]);
+                    if (mv < val) { mv = val; m = i; }
+                }
+                indR[idx] = m;
+            }
+            if (idx > 0) {
+                for (m = 0, mv = fabsf(A[0][idx]), i = 1; i < idx; ++i) {
+                    float val = fabsf(A[i][idx]);
+                    if (mv < val) { mv = val; m = i; }
+                }
+                indC[idx] = m;
+            }
+        }
+    }
+    for (k = 0; k < N - 1; ++k) {
+        m = k;
+        for (i = k + 1; i < N; ++i) if (W[m] < W[i]) m = i;
+        if (k != m) {
+            float t = W[m]; W[m] = W[k]; W[k] = t;
+            for (i = 0; i < N; ++i) { t = V[m * N + i]; V[m * N + i] = V[k * N + i]; V[k * N + i] = t; }
+        }
+    }
+}
+
+static void lo_corner_point(const lo_s2m_config *cfg, const float T[12], const float *pointOri,
+                            const float *map_xyz, size_t n_map, const lo_kdtree *tree,
+                            uint8_t *flag, float *coeff, int32_t *nn)
+{
+    float pointSel[3];
+    int32_t ind[5];
+    float sq[5];
+    *flag = 0;
+    coeff[0] = coeff[1] = coeff[2] = coeff[3] = 0.0f;
+    for (int j = 0; j < 5; ++j) nn[j] = -1;
+    lo_point_associate(T, pointOri, pointSel);
+    if (cfg->knn_mode == 0 || tree == NULL) lo_knn5_brute(map_xyz, n_map, pointSel, ind, sq);
+    else                                    lo_kdtree_knn5(tree, pointSel, ind, sq);
+    if (!((double)sq[4] < (double)cfg->max_sq_dist)) return;
+    for (int j = 0; j < 5; ++j) nn[j] = ind[j];
+
+    float cx = 0, cy = 0, cz = 0;
+    for (int j = 0; j < 5; ++j) {
+        cx += map_xyz[3 * (size_t)ind[j] + 0]; cy += map_xyz[3 * (size_t)ind[j] + 1]; cz += map_xyz[3 * (size_t)ind[j] + 2];
+    }
+    cx /= 5; cy /= 5; cz /= 5;
+    float a11 = 0, a12 = 0, a13 = 0, a22 = 0, a23 = 0, a33 = 0;
+    for (int j = 0; j < 5; ++j) {
+        float ax = map_xyz[3 * (size_t)ind[j] + 0] - cx;
+        float ay = map_xyz[3 * (size_t)ind[j] + 1] - cy;
+        float az = map_xyz[3 * (size_t)ind[j] + 2] - cz;
+        a11 += ax * ax; a12 += ax * ay; a13 += ax * az;
+        a22 += ay * ay; a23 += ay * az;
+        a33 += az * az;
+    }
+    a11 /= 5; a12 /= 5; a13 /= 5; a22 /= 5; a23 /= 5; a33 /= 5;
+    float A1[9] = { a11, a12, a13, a12, a22, a23, a13, a23, a33 }, D1[3], V1[9];
+    lo_eigen3_sym(A1, D1, V1);
+    if (!(D1[0] > 3 * D1[1])) return;
+
+    float x0 = pointSel[0], y0 = pointSel[1], z0 = pointSel[2];
+    /* `cx + 0.1 * v`: 0.1 is a double literal, the sum is rounded to float once */
+    float x1 = (float)(cx + 0.1 * V1[0]), y1 = (float)(cy + 0.1 * V1[1]), z1 = (float)(cz + 0.1 * V1[2]);
+    float x2 = (float)(cx - 0.1 * V1[0]), y2 = (float)(cy - 0.1 * V1[1]), z2 = (float)(cz - 0.1 * V1[2]);
+
+    float m1 = (x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1);
+    float m2 = (x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1);
+    float m3 = (y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1);
+    float a012 = sqrtf(m1 * m1 + m2 * m2 + m3 * m3);
+    float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+    float la = ((y1 - y2) * m1 + (z1 - z2) * m2) / a012 / l12;
+    float lb = -((x1 - x2) * m1 - (z1 - z2) * m3) / a012 / l12;
+    float lc = -((x1 - x2) * m2 + (y1 - y2) * m3) / a012 / l12;
+    float ld2 = a012 / l12;
+    float s = (float)(1 - cfg->weight * (double)fabsf(ld2));
+    coeff[0] = s * la; coeff[1] = s * lb; coeff[2] = s * lc; coeff[3] = s * ld2;
+    if ((double)s > cfg->min_s) *flag = 1;
+}
+
+void lo_corner_optimization(const lo_s2m_config *cfg, const float pose[6],
+                            const float *scan_xyz, size_t n_scan,
+                            const float *map_xyz, size_t n_map, const lo_kdtree *tree,
+                            uint8_t *flag, float *coeff, int32_t *nn_idx)
+{
+    float T[12];
+    lo_get_transformation(pose[3], pose[4], pose[5], pose[0], pose[1], pose[2], T, cfg->trig_mode);
+    long n = (long)n_scan;
+    int nt = cfg->n_threads > 0 ? cfg->n_threads : 1;
+    (void)nt;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nt) schedule(static)
+#endif
+    for (long i = 0; i < n; ++i)
+        lo_corner_point(cfg, T, scan_xyz + 3 * i, map_xyz, n_map, tree, flag + i, coeff + 4 * i, nn_idx + 5 * i);
+}
+
+/* scan2MapOptimization with both residual types (upstream order: corner correspondences first,
+ * then surf, in combineOptimizationCoeffs).  n_corner == 0 reduces to lo_scan2map. */
+int lo_scan2map_cs(const lo_s2m_config *cfg,
+                   const float *corner_xyz, size_t n_corner, const float *cmap_xyz, size_t n_cmap,
+                   const float *surf_xyz, size_t n_surf, const float *smap_xyz, size_t n_smap,
+                   float pose[6], float matP_io[36], int32_t *is_degenerate_io, lo_s2m_result *res,
+                   int corr_iter, uint8_t *cflag_out, float *ccoeff_out, int32_t *cnn_out)
+{
+    memset(res, 0, sizeof(*res));
+    res->is_degenerate = *is_degenerate_io;
+    memcpy(res->matP, matP_io, sizeof(float) * 36);
+    if (!((long)n_surf > (long)cfg->min_scan_pts)) { res->status = LO_TOO_FEW_POINTS; return res->status; }
+    lo_kdtree *stree = cfg->knn_mode == 1 ? lo_kdtree_build(smap_xyz, n_smap) : NULL;
+    lo_kdtree *ctree = (cfg->knn_mode == 1 && n_corner) ? lo_kdtree_build(cmap_xyz, n_cmap) : NULL;
+    size_t n_all = n_corner + n_surf;
+    uint8_t *flag = (uint8_t *)malloc(n_all ? n_all : 1);
+    float *coeff = (float *)malloc(sizeof(float) * 4 * (n_all ? n_all : 1));
+    int32_t *nn = (int32_t *)malloc(sizeof(int32_t) * 5 * (n_all ? n_all : 1));
+    float *ori_sel = (float *)malloc(sizeof(float) * 3 * (n_all ? n_all : 1));
+    float *coeff_sel = (float *)malloc(sizeof(float) * 4 * (n_all ? n_all : 1));
+    int max_iters = cfg->max_iters > 32 ? 32 : cfg->max_iters;
+    for (int it = 0; it < max_iters; ++it) {
+        if (n_corner) lo_corner_optimization(cfg, pose, corner_xyz, n_corner, cmap_xyz, n_cmap, ctree, flag, coeff, nn);
+        lo_surf_optimization(cfg, pose, surf_xyz, n_surf, smap_xyz, n_smap, stree,
+                             flag + n_corner, coeff + 4 * n_corner, nn + 5 * n_corner);
+        if (it == corr_iter && n_corner) {
+            if (cflag_out)  memcpy(cflag_out, flag, n_corner);
+            if (ccoeff_out) memcpy(ccoeff_out, coeff, sizeof(float) * 4 * n_corner);
+            if (cnn_out)    memcpy(cnn_out, nn, sizeof(int32_t) * 5 * n_corner);
+        }
+        int nc = 0;
+        for (size_t i = 0; i < n_all; ++i)
+            if (flag[i]) {
+                const float *src = i < n_corner ? corner_xyz + 3 * i : surf_xyz + 3 * (i - n_corner);
+                memcpy(ori_sel + 3 * (size_t)nc, src, sizeof(float) * 3);
+                memcpy(coeff_sel + 4 * (size_t)nc, coeff + 4 * i, sizeof(float) * 4);
+                ++nc;
+            }
+        res->n_corr_iter[it] = nc;
+        res->n_corr_last = nc;
+        int conv = lo_lm_optimization(cfg, it, ori_sel, coeff_sel, nc, pose, matP_io, is_degenerate_io,
+                                      nc >= cfg->min_corr ? res->AtA : NULL, nc >= cfg->min_corr ? res->AtB : NULL);
+        memcpy(res->pose_iter[it], pose, sizeof(float) * 6);
+        res->iters = it + 1;
+        if (conv) { res->converged = 1; if (!cfg->force_all_iters) break; }
+    }
+    res->is_degenerate = *is_degenerate_io;
+    memcpy(res->matP, matP_io, sizeof(float) * 36);
+    res->status = (res->n_corr_last < cfg->min_corr) ? LO_TOO_FEW_CORR : LO_OK;
+    free(flag); free(coeff); free(nn); free(ori_sel); free(coeff_sel);
+    lo_kdtree_free(stree); lo_kdtree_free(ctree);
+    return res->status;
+}

@@ -196,6 +196,19 @@ void lo_transform_point_cloud(const float *in_xyzi, size_t n, const float pose[6
 /* pcl::VoxelGrid centroid filter (MO:1605-1611, MO:1581-1583); out has room for n points */
 int  lo_voxel_grid(const float *in_xyzi, size_t n, float leaf, float *out_xyzi, size_t *n_out);
 
+/* ---- EXTENSION beyond the reference: point-to-line residuals (upstream LIO-SAM
+ * cornerOptimization; absent from this fork; parity unpinned) ---- */
+void lo_eigen3_sym(const float A[9], float evals[3], float evecs[9]);
+void lo_corner_optimization(const lo_s2m_config *cfg, const float pose[6],
+                            const float *scan_xyz, size_t n_scan,
+                            const float *map_xyz, size_t n_map, const lo_kdtree *tree,
+                            uint8_t *flag, float *coeff, int32_t *nn_idx);
+int lo_scan2map_cs(const lo_s2m_config *cfg,
+                   const float *corner_xyz, size_t n_corner, const float *cmap_xyz, size_t n_cmap,
+                   const float *surf_xyz, size_t n_surf, const float *smap_xyz, size_t n_smap,
+                   float pose[6], float matP_io[36], int32_t *is_degenerate_io, lo_s2m_result *res,
+                   int corr_iter, uint8_t *cflag_out, float *ccoeff_out, int32_t *cnn_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,12 @@ class Oracle:
         L.lo_calculate_smoothness.argtypes = [_f32p, C.c_size_t, _f32p, C.c_void_p, C.c_void_p]
         L.lo_transform_point_cloud.argtypes = [_f32p, C.c_size_t, _f32p, _f32p, C.c_int]
         L.lo_voxel_grid.argtypes = [_f32p, C.c_size_t, C.c_float, _f32p, C.POINTER(C.c_size_t)]
+        L.lo_eigen3_sym.argtypes = [_f32p, _f32p, _f32p]
+        L.lo_corner_optimization.argtypes = [C.POINTER(S2MConfig), _f32p, _f32p, C.c_size_t, _f32p,
+                                             C.c_size_t, C.c_void_p, _u8p, _f32p, _i32p]
+        L.lo_scan2map_cs.argtypes = [C.POINTER(S2MConfig), _f32p, C.c_size_t, _f32p, C.c_size_t, _f32p, C.c_size_t,
+                                     _f32p, C.c_size_t, _f32p, _f32p, _i32p, C.POINTER(S2MResult),
+                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
 
     # ---- helpers -----------------------------------------------------------
     def default_config(self, **kw):
@@ -261,3 +267,42 @@ class Oracle:
         n_out = C.c_size_t()
         rc = self.lib.lo_voxel_grid(xyzi.reshape(-1), len(xyzi), leaf, out.reshape(-1), C.byref(n_out))
         return out[:n_out.value].copy(), rc
+
+    # ---- extension beyond the reference: point-to-line residuals (upstream LIO-SAM) ----
+    def eigen3(self, A):
+        w = np.zeros(3, np.float32)
+        v = np.zeros(9, np.float32)
+        self.lib.lo_eigen3_sym(np.ascontiguousarray(A, np.float32).reshape(9), w, v)
+        return w, v.reshape(3, 3)
+
+    def corner_optimization(self, cfg, pose, scan_xyz, map_xyz):
+        scan_xyz = np.ascontiguousarray(scan_xyz, np.float32)
+        map_xyz = np.ascontiguousarray(map_xyz, np.float32)
+        n = len(scan_xyz)
+        flag = np.zeros(n, np.uint8); coeff = np.zeros((n, 4), np.float32); nn = np.zeros((n, 5), np.int32)
+        tree = self.lib.lo_kdtree_build(map_xyz, len(map_xyz)) if cfg.knn_mode == 1 else None
+        try:
+            self.lib.lo_corner_optimization(C.byref(cfg), np.ascontiguousarray(pose, np.float32), scan_xyz, n,
+                                            map_xyz, len(map_xyz), tree, flag, coeff.reshape(-1), nn.reshape(-1))
+        finally:
+            if tree:
+                self.lib.lo_kdtree_free(tree)
+        return flag, coeff, nn
+
+    def scan2map_cs(self, cfg, corner_scan, corner_map, surf_scan, surf_map, pose, corr_iter=-1):
+        cs = np.ascontiguousarray(corner_scan, np.float32).reshape(-1, 3)
+        cm = np.ascontiguousarray(corner_map, np.float32).reshape(-1, 3)
+        ss = np.ascontiguousarray(surf_scan, np.float32)
+        sm = np.ascontiguousarray(surf_map, np.float32)
+        pose = np.array(pose, np.float32).copy()
+        matP = np.zeros(36, np.float32); deg = np.zeros(1, np.int32); res = S2MResult()
+        corr, a, b, c = None, None, None, None
+        if corr_iter >= 0 and len(cs):
+            flag = np.zeros(len(cs), np.uint8); coeff = np.zeros((len(cs), 4), np.float32)
+            nn = np.full((len(cs), 5), -1, np.int32)
+            corr = (flag, coeff, nn); a, b, c = flag.ctypes.data, coeff.ctypes.data, nn.ctypes.data
+        dummy = np.zeros(3, np.float32)
+        self.lib.lo_scan2map_cs(C.byref(cfg), cs.reshape(-1) if len(cs) else dummy, len(cs),
+                                cm.reshape(-1) if len(cm) else dummy, len(cm), ss.reshape(-1), len(ss),
+                                sm.reshape(-1), len(sm), pose, matP, deg, C.byref(res), corr_iter, a, b, c)
+        return pose, res, matP.reshape(6, 6), corr
