@@ -53,6 +53,23 @@ public:
         return rc;
     }
 
+    // ---- extension beyond this reference (upstream LIO-SAM) ----
+    // kdtreeCornerFromMap->setInputCloud(laserCloudCornerFromMapDS)
+    void setInputCloudCorner(const void* pts, size_t n, size_t stride_bytes)
+    {
+        check(lio_s2m_set_corner_map(h_, pts, n, stride_bytes), "lio_s2m_set_corner_map");
+    }
+    // upstream loop body: cornerOptimization(); surfOptimization(); combineOptimizationCoeffs(); LMOptimization(iterCount)
+    int scan2MapOptimization(const void* laserCloudCornerLastDS, size_t n_corner,
+                             const void* laserCloudSurfLastDS, size_t n_surf, size_t stride_bytes)
+    {
+        const int rc = lio_s2m_register_cs(h_, laserCloudCornerLastDS, n_corner, laserCloudSurfLastDS, n_surf,
+                                           stride_bytes, transformTobeMapped, &last);
+        if (rc < 0) check(rc, "lio_s2m_register_cs");
+        isDegenerate = last.is_degenerate != 0;
+        return rc;
+    }
+
     // transformUpdate + constraintTransformation, MO:1867-1907
     void transformUpdate(bool imuAvailable, int imuType, float imuRollInit, float imuPitchInit,
                          float imuRPYWeight, float rotation_tollerance, float z_tollerance)

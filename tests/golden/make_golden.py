@@ -46,6 +46,17 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), scan=scan, map=case["map"],
                             pose_init=q["pose_init"], pose_true=q["pose_true"], **out)
         print(name, scan.shape, case["map"].shape, out["pose"], out["iters"], out["is_degenerate"])
+    # ---- EXTENSION: corner + surf registration, upstream LIO-SAM semantics
+    case = synth.add_corners(synth.make_case("vlp16", n_keyframes=5, seed=23, device="cpu"), "vlp16", seed=23)
+    q = case["queries"][0]
+    scan = q["scan"][::2].copy()
+    cfg = orc.default_config(knn_mode=0)
+    pose, res, matP, corr = orc.scan2map_cs(cfg, q["corners"], case["corner_map"], scan, case["map"], q["pose_init"], corr_iter=0)
+    np.savez_compressed(os.path.join(HERE, "s2m_corner.npz"), scan=scan, map=case["map"], corners=q["corners"],
+                        corner_map=case["corner_map"], pose_init=q["pose_init"], pose_true=q["pose_true"],
+                        pose=pose, iters=res.iters, n_corr_iter=np.array(res.n_corr_iter), matP=matP,
+                        AtA=np.array(res.AtA, np.float32), cflag0=corr[0], ccoeff0=corr[1], cnn0=corr[2])
+    print("s2m_corner", scan.shape, q["corners"].shape, case["corner_map"].shape, pose, res.iters)
     # ---- deskew + curvature
     boxes = synth.make_scene(5, length=60.0)
     sc = synth.cast_scan(boxes, [0.01, -0.02, 0.3, 10.0, 0.2, synth.SENSOR_HEIGHT], "vlp16", seed=3,

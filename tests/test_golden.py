@@ -32,6 +32,19 @@ def test_oracle_reproduces_golden(oracle, name):
     assert int(_load("s2m_corridor")["is_degenerate"]) == 1 and int(_load("s2m_street")["is_degenerate"]) == 0
 
 
+def test_oracle_reproduces_corner_golden(oracle):
+    """Extension: brute-force fixture vs kd-tree / threaded oracle."""
+    g = _load("s2m_corner")
+    cfg = oracle.default_config(knn_mode=1, n_threads=4)
+    pose, res, matP, corr = oracle.scan2map_cs(cfg, g["corners"], g["corner_map"], g["scan"], g["map"], g["pose_init"], corr_iter=0)
+    np.testing.assert_array_equal(pose, g["pose"])
+    assert res.iters == int(g["iters"])
+    np.testing.assert_array_equal(np.array(res.n_corr_iter), g["n_corr_iter"])
+    for a, k in zip(corr, ("cflag0", "ccoeff0", "cnn0")):
+        np.testing.assert_array_equal(a, g[k])
+    assert np.abs(pose - g["pose_true"]).max() < 0.05
+
+
 def test_oracle_prepare_golden(oracle):
     import oracle.oracle as om
     g = _load("prepare")
@@ -72,6 +85,25 @@ def test_gpu_reproduces_golden(pkg, name):
             np.testing.assert_array_equal(coeff[flag == 1].view(np.uint32), g["coeff0"][flag == 1].view(np.uint32))
         s2m.close()
     assert all(matp_exact), "matP differs from the oracle in the last bits"
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_corner_golden(pkg):
+    g = _load("s2m_corner")
+    s2m = pkg.ScanToMap(record_corr_iter=0)
+    s2m.set_map(g["map"])
+    s2m.set_corner_map(g["corner_map"])
+    pose, res, rc = s2m.scan2MapOptimizationCS(g["corners"], g["scan"], g["pose_init"])
+    assert rc == 0 and res.iters == int(g["iters"])
+    assert list(res.n_corr_iter) == list(g["n_corr_iter"])
+    np.testing.assert_allclose(pose[3:], g["pose"][3:], atol=1e-5)
+    np.testing.assert_allclose(pose[:3], g["pose"][:3], atol=1e-6)
+    flag, coeff, nn = s2m.get_corner_correspondences(0)
+    np.testing.assert_array_equal(flag, g["cflag0"])
+    np.testing.assert_array_equal(nn, g["cnn0"])
+    gated = nn[:, 0] >= 0
+    np.testing.assert_array_equal(coeff[gated].view(np.uint32), g["ccoeff0"][gated].view(np.uint32))
+    s2m.close()
 
 
 @pytest.mark.gpu
