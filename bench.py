@@ -129,9 +129,15 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_SHARDED=1 drives the N>1 code path (process group, broadcasts, ShardedRunner, all-reduce
+    # per GN iteration) with a single rank: a rehearsal of the RCCL calls on a one-GPU box, not a bench mode
+    sharded = world > 1 or os.environ.get("BENCH_FORCE_SHARDED") == "1"
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # RCCL over xGMI; BENCH_BACKEND=gloo only exists to rehearse the N>1 path with ranks sharing one GPU
         backend = os.environ.get("BENCH_BACKEND", "nccl")
         if backend == "nccl":
@@ -145,7 +151,7 @@ def main():
 
     pkg = importlib.import_module("lio-slam_amd")
     synth = importlib.import_module("lio-slam_amd.synth")
-    multi = importlib.import_module("lio-slam_amd.multigpu") if world > 1 else None
+    multi = importlib.import_module("lio-slam_amd.multigpu") if sharded else None
 
     # ---------------------------------------------------------------- data
     B = args.batch * world
@@ -171,7 +177,7 @@ def main():
                      scans=np.concatenate(sc), lens=np.array([len(x) for x in sc]))
         return case["map"], sc, p0, pt
 
-    if world == 1:
+    if not sharded:
         map_xyz, scans, poses0, poses_true = generate()
     else:
         # rank 0 generates, everyone receives the SAME bytes (the ranks must agree on the map
@@ -204,7 +210,7 @@ def main():
     # -------------------------------------------------------------- engine
     kcfg = dict(device_id=local_rank, profile=1, use_graph=1 if args.graph else 0, graph_iters=max(args.graph, 1), lookahead=args.lookahead, kernel_variant=args.variant,
                 use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch)
-    if world > 1:
+    if sharded:
         runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2, **kcfg)
         runner.upload(scans)
         s2m = runner.handles[0]
@@ -275,7 +281,7 @@ def main():
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath) and world == 1:
+    if os.path.exists(tpath) and not sharded:
         tj = json.load(open(tpath))
         if (tj.get("scans_per_step"), tj.get("N_m")) == (B, int(len(map_xyz))):
             traffic = tj["hbm_bytes_per_launch"]      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see DESIGN.md
@@ -292,7 +298,7 @@ def main():
                         f"configs[4] batched form)",
             "scans_per_step": B, "N_s_mean": float(n_s.mean()), "N_m": int(len(map_xyz)),
             "gn_iters_mean": float(iters.mean()), "gn_iters_max": int(iters.max()),
-            "parallelism": "single GPU" if world == 1 else
+            "parallelism": "single GPU" if not sharded else
             (f"map sharded x{world} (slabs + halo, owner-computes)" if args.shard == "map" else
              f"map replicated, scan workgroups dealt over {world} ranks") + " + RCCL all-reduce of JtJ/Jtr per GN iteration",
             "kernel": {"points_per_thread": int(args.variant), "lds_staging": int(args.lds),
@@ -320,7 +326,7 @@ def main():
             out["pose_rmse_vs_cpu"] = {"trans_m": rt, "rot_rad": rr, "scans": k,
                                        "bit_identical": int(sum(np.array_equal(a, b) for a, b in zip(poses[:k], cpu_poses))),
                                        "iters_equal": bool(list(iters[:k]) == list(cpu_iters))}
-        if keyframes and world == 1:
+        if keyframes and not sharded:
             # feeder: extractCloud MO:1556-1588 on the GPU, host clouds in, map resident out
             kc = [np.concatenate([c, np.zeros((len(c), 1), np.float32)], 1) for c, _ in keyframes]
             kp = np.stack([p for _, p in keyframes])
@@ -339,7 +345,7 @@ def main():
                                    "keyframes": len(kc), "points_in": int(sum(len(c) for c in kc)), "points_out": int(n_asm)}
             store.close()
             asm.close()
-        if args.latency and world == 1:
+        if args.latency and not sharded:
             lat = pkg.ScanToMap(device_id=local_rank)
             lat.set_map(map_xyz)
             for i in range(3):
