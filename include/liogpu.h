@@ -248,6 +248,34 @@ int  lio_deskew(const lio_deskew_config *cfg, const void *pts, size_t n, size_t 
 int  lio_curvature(int32_t device_id, const float *range, size_t n, float *curvature,
                    int32_t *neighbor_picked, int32_t *label);
 
+/* The rest of FeatureExtraction::laserCloudInfoHandler FE:67-79: calculateSmoothness FE:81-101,
+ * markOccludedPoints FE:103-139 and extractFeatures FE:141-238 on the device, consuming the
+ * cloud_info arrays (MSG:4-8) as the reference does.
+ * cloud: extractedCloud records (x,y,z @0,4,8, intensity @16), n points, ring-major.
+ * startRingIndex/endRingIndex: cfg->N_SCAN entries.  Rings must own disjoint, ascending index
+ * windows [start-5, end+4] (what upstream's cloudExtraction produces); at most 4086 points per
+ * ring and 1024 per sector; columns must fit int16.
+ * corner_out: room for 120 * N_SCAN records (FE:171: <= 20 per sector); surface_out: room for n.
+ * curvature / neighbor_picked / label (each n entries, may be NULL) receive cloudCurvature,
+ * cloudNeighborPicked and cloudLabel as the reference leaves them after the handler.
+ * Defined here where the reference is not (see oracle/lio_oracle.c lo_extract_features): the
+ * flag arrays start from zero for every scan, equal curvatures keep ascending point index
+ * (std::sort FE:162 leaves their order open), and a suppression walk FE:178-193 stops at the
+ * array boundary instead of indexing pointColInd[-1]. */
+typedef struct lio_feature_config {
+    int32_t N_SCAN;          /* UT:164 */
+    float   edgeThreshold;   /* UT:186, 1.0 in config/*.yaml */
+    float   surfThreshold;   /* UT:187, 0.1 */
+    float   surfLeafSize;    /* mappingSurfLeafSize FE:56 */
+    int32_t device_id;
+} lio_feature_config;
+void lio_feature_default_config(lio_feature_config *cfg);
+int  lio_extract_features(const lio_feature_config *cfg, const void *cloud, size_t n, size_t stride_bytes,
+                          const int32_t *startRingIndex, const int32_t *endRingIndex,
+                          const int32_t *pointColInd, const float *pointRange,
+                          void *corner_out, size_t *n_corner, void *surface_out, size_t *n_surface,
+                          size_t out_stride_bytes, float *curvature, int32_t *neighbor_picked, int32_t *label);
+
 /* ------------------------------------------------ local-map assembly (feeders) */
 /* pcl::VoxelGrid<PointXYZI>::filter as used by downsampleCurrentScan MO:1605-1611
  * (downSizeFilterSurf, leaf = mappingSurfLeafSize) and MO:1581-1583: centroid per

@@ -66,6 +66,11 @@ class DeskewConfig(C.Structure):
     ]
 
 
+class FeatureConfig(C.Structure):
+    _fields_ = [("N_SCAN", C.c_int32), ("edgeThreshold", C.c_float), ("surfThreshold", C.c_float),
+                ("surfLeafSize", C.c_float), ("device_id", C.c_int32)]
+
+
 def lib_path():
     return os.path.join(_HERE, "libliogpu.so")
 
@@ -94,7 +99,7 @@ EXPORTS = [
     "lio_curvature", "lio_s2m_debug_stamps", "lio_s2m_batch_poll_active", "lio_voxel_grid", "lio_assemble_map", "lio_kf_store_create", "lio_kf_store_destroy", "lio_kf_store_add",
     "lio_kf_store_count", "lio_assemble_map_resident", "lio_s2m_set_scan_shard",
     "lio_s2m_set_corner_map", "lio_s2m_batch_upload_corners", "lio_s2m_register_cs",
-    "lio_s2m_get_corner_correspondences",
+    "lio_s2m_get_corner_correspondences", "lio_feature_default_config", "lio_extract_features",
 ]
 
 
@@ -148,6 +153,10 @@ def load_library():
     L.lio_deskew.argtypes = [C.POINTER(DeskewConfig), vp, sz, sz, f64, dp, dp, dp, dp, i32, vp, sz,
                              C.POINTER(sz)]
     L.lio_curvature.argtypes = [i32, vp, sz, vp, vp, vp]
+    L.lio_feature_default_config.argtypes = [C.POINTER(FeatureConfig)]
+    L.lio_feature_default_config.restype = None
+    L.lio_extract_features.argtypes = [C.POINTER(FeatureConfig), vp, sz, sz, vp, vp, vp, vp, vp, C.POINTER(sz), vp,
+                                       C.POINTER(sz), sz, vp, vp, vp]
     L.lio_s2m_debug_stamps.argtypes = [vp, vp, sz]
     L.lio_voxel_grid.argtypes = [i32, vp, sz, sz, f32, vp, sz, C.POINTER(sz)]
     L.lio_kf_store_create.argtypes = [i32, C.POINTER(vp)]
@@ -414,6 +423,38 @@ def curvature(rng, device_id=0):
     _check(load_library().lio_curvature(device_id, r.ctypes.data, len(r), curv.ctypes.data,
                                         picked.ctypes.data, label.ctypes.data), "lio_curvature")
     return curv, picked, label
+
+
+# markOccludedPoints + extractFeatures, FE:103-238 (with calculateSmoothness: the whole handler FE:67-77)
+def extract_features(cloud_xyzi, start_ring, end_ring, point_col, point_range, device_id=0, **cfg_overrides):
+    """cloud_xyzi [n,4] -> dict(corner [n_c,4], surface [n_s,4], curvature, picked, label)."""
+    L = load_library()
+    cfg = FeatureConfig()
+    L.lio_feature_default_config(C.byref(cfg))
+    cfg.N_SCAN = len(start_ring)
+    cfg.device_id = device_id
+    for k, v in cfg_overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    rec = _as_xyzi_records(np.asarray(cloud_xyzi, np.float32).reshape(-1, 4))
+    n = len(rec)
+    sr = np.ascontiguousarray(start_ring, np.int32)
+    er = np.ascontiguousarray(end_ring, np.int32)
+    col = np.ascontiguousarray(point_col, np.int32)
+    rng = np.ascontiguousarray(point_range, np.float32)
+    corner = np.zeros((120 * max(cfg.N_SCAN, 1), 8), np.float32)
+    surf = np.zeros((max(n, 1), 8), np.float32)
+    curv = np.zeros(max(n, 1), np.float32)
+    picked = np.zeros(max(n, 1), np.int32)
+    label = np.zeros(max(n, 1), np.int32)
+    nc, ns = C.c_size_t(0), C.c_size_t(0)
+    _check(L.lio_extract_features(C.byref(cfg), rec.ctypes.data, n, 32, sr.ctypes.data, er.ctypes.data,
+                                  col.ctypes.data, rng.ctypes.data, corner.ctypes.data, C.byref(nc),
+                                  surf.ctypes.data, C.byref(ns), 32, curv.ctypes.data, picked.ctypes.data,
+                                  label.ctypes.data), "lio_extract_features")
+    return {"corner": _from_records(corner, nc.value), "surface": _from_records(surf, ns.value),
+            "curvature": curv[:n], "picked": picked[:n], "label": label[:n]}
 
 
 def _as_xyzi_records(a):

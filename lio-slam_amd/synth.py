@@ -327,3 +327,25 @@ def add_corners(case, sensor="vlp16", seed=BASE_SEED, map_leaf=0.2,
     for q, qu in enumerate(case["queries"]):
         qu["corners"] = cast_edges(case["boxes"], qu["pose_true"], sensor, seed=seed + 7000 + q)
     return case
+
+
+# ------------------------------------------------------- cloud_info arrays (A4)
+# The reference's featureExtraction consumes startRingIndex / endRingIndex / pointColInd / pointRange
+# (MSG:4-8) but nothing in it produces them.  This builds them the way upstream
+# LIO-SAM's cloudExtraction does from an organised sweep: ring-major, ascending column, one return per
+# (ring, column) cell; startRingIndex = first + 5, endRingIndex = last - 5.
+def organize_scan(sc):
+    """sc = cast_scan() dict -> dict(cloud [n,4] xyzi, start_ring, end_ring, col, range) in ring-major order."""
+    n_rings = int(sc["n_rings"])
+    order = np.lexsort((sc["col"], sc["ring"]))
+    ring = sc["ring"][order].astype(np.int64)
+    cloud = np.concatenate([sc["xyz"][order], sc["intensity"][order][:, None]], 1).astype(np.float32)
+    start = np.zeros(n_rings, np.int32)
+    end = np.zeros(n_rings, np.int32)
+    count = 0
+    for i in range(n_rings):
+        start[i] = count - 1 + 5
+        count += int((ring == i).sum())
+        end[i] = count - 1 - 5
+    return {"cloud": cloud, "start_ring": start, "end_ring": end,
+            "col": sc["col"][order].astype(np.int32), "range": sc["range"][order].astype(np.float32)}

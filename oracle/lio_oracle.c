@@ -1149,6 +1149,147 @@ int lo_voxel_grid(const float *in_xyzi, size_t n, float leaf, float *out_xyzi, s
 }
 
 /* =========================================================================
+ * featureExtraction.cpp, the rest of laserCloudInfoHandler FE:67-79:
+ * markOccludedPoints FE:103-139 and extractFeatures FE:141-238, consuming the cloud_info arrays
+ * (startRingIndex, endRingIndex, pointColInd, pointRange; MSG:4-8) exactly as the reference does.
+ * The reference has no PRODUCER of those arrays, so the tests feed synthetic ones.
+ *
+ * Three places where the reference's behaviour is not a function of its inputs, and what is fixed here:
+ *  - with the producer upstream LIO-SAM has (startRingIndex[0] = 0 - 1 + 5 = 4), ring 0's first sector
+ *    starts at index 4: FE:183/215 then read pointColInd[-1] and FE:186/221 may write
+ *    cloudNeighborPicked[-1] (and the same past the end for the last ring).  Here a neighbour walk
+ *    stops at the array boundary, and curvature outside [5, n-5) is 0.
+ *  - cloudNeighborPicked / cloudLabel / cloudSmoothness are `new[]`-allocated and only indices
+ *    [5, n-5) are reset per scan (FE:95-99): indices outside keep whatever earlier scans (or the
+ *    allocator) left.  Here every scan starts from zeros.
+ *  - std::sort FE:162 does not define the order of equal curvatures.  Here ties keep ascending point
+ *    index (a stable sort), which is one of the orders std::sort may produce.
+ * ========================================================================= */
+typedef struct { float value; int32_t ind; } lo_smooth;
+
+static void lo_sort_smooth(lo_smooth *a, int n)      /* stable insertion/merge: n <= a few hundred */
+{
+    if (n < 2) return;
+    lo_smooth *tmp = (lo_smooth *)malloc(sizeof(lo_smooth) * (size_t)n);
+    for (int w = 1; w < n; w *= 2) {
+        for (int lo = 0; lo < n; lo += 2 * w) {
+            int mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            int i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) tmp[k++] = (a[j].value < a[i].value) ? a[j++] : a[i++];
+            while (i < mid) tmp[k++] = a[i++];
+            while (j < hi) tmp[k++] = a[j++];
+        }
+        memcpy(a, tmp, sizeof(lo_smooth) * (size_t)n);
+    }
+    free(tmp);
+}
+
+void lo_mark_occluded(const float *pointRange, const int32_t *pointColInd, size_t n, int32_t *picked)
+{
+    const int cloudSize = (int)n;
+    for (int i = 5; i < cloudSize - 6; ++i) {                                   /* FE:107 */
+        float depth1 = pointRange[i], depth2 = pointRange[i + 1];
+        int columnDiff = abs((int)(pointColInd[i + 1] - pointColInd[i]));
+        if (columnDiff < 10) {                                                  /* FE:114 */
+            if ((double)(depth1 - depth2) > 0.3) {
+                for (int l = -5; l <= 0; ++l) picked[i + l] = 1;
+            } else if ((double)(depth2 - depth1) > 0.3) {
+                for (int l = 1; l <= 6; ++l) picked[i + l] = 1;
+            }
+        }
+        float diff1 = fabsf(pointRange[i - 1] - pointRange[i]);                 /* FE:133-134 */
+        float diff2 = fabsf(pointRange[i + 1] - pointRange[i]);
+        if ((double)diff1 > 0.02 * (double)pointRange[i] && (double)diff2 > 0.02 * (double)pointRange[i])
+            picked[i] = 1;
+    }
+}
+
+/* Whole handler FE:67-77.  cloud = extractedCloud as (x,y,z,intensity)[n].  Outputs sized n each;
+ * curvature/picked/label may be NULL.  Returns 0, or -1 when a ring's [start, end] lies outside [0, n-1]. */
+int lo_extract_features(const float *cloud_xyzi, size_t n, int n_scan,
+                        const int32_t *startRingIndex, const int32_t *endRingIndex,
+                        const int32_t *pointColInd, const float *pointRange,
+                        float edgeThreshold, float surfThreshold, float surfLeaf,
+                        float *corner_xyzi, size_t *n_corner, float *surf_xyzi, size_t *n_surf,
+                        float *curvature_out, int32_t *picked_out, int32_t *label_out)
+{
+    *n_corner = 0; *n_surf = 0;
+    for (int i = 0; i < n_scan; ++i)
+        if (endRingIndex[i] >= startRingIndex[i] && (startRingIndex[i] < 0 || (long)endRingIndex[i] > (long)n - 1)) return -1;
+    size_t nn = n ? n : 1;
+    float *curv = (float *)calloc(nn, sizeof(float));
+    int32_t *picked = (int32_t *)calloc(nn, sizeof(int32_t)), *label = (int32_t *)calloc(nn, sizeof(int32_t));
+    lo_smooth *sm = (lo_smooth *)calloc(nn, sizeof(lo_smooth));
+    float *ring_in = (float *)malloc(sizeof(float) * 4 * nn), *ring_out = (float *)malloc(sizeof(float) * 4 * nn);
+    if (n) lo_calculate_smoothness(pointRange, n, curv, NULL, NULL);            /* FE:81-101 */
+    for (size_t i = 0; i < n; ++i) { sm[i].value = curv[i]; sm[i].ind = (int32_t)i; }
+    lo_mark_occluded(pointRange, pointColInd, n, picked);
+
+    for (int i = 0; i < n_scan; ++i) {                                          /* FE:149 */
+        size_t n_ring = 0;
+        for (int j = 0; j < 6; ++j) {
+            int sp = (startRingIndex[i] * (6 - j) + endRingIndex[i] * j) / 6;                 /* FE:156 */
+            int ep = (startRingIndex[i] * (5 - j) + endRingIndex[i] * (j + 1)) / 6 - 1;       /* FE:157 */
+            if (sp >= ep) continue;
+            lo_sort_smooth(sm + sp, ep - sp);                                   /* FE:162: [sp, ep) -- element ep stays */
+            int largestPickedNum = 0;
+            for (int k = ep; k >= sp; --k) {                                    /* FE:165 */
+                int ind = sm[k].ind;
+                if (picked[ind] == 0 && curv[ind] > edgeThreshold) {
+                    ++largestPickedNum;
+                    if (largestPickedNum <= 20) {
+                        label[ind] = 1;
+                        memcpy(corner_xyzi + 4 * (*n_corner), cloud_xyzi + 4 * (size_t)ind, sizeof(float) * 4);
+                        ++*n_corner;
+                    } else {
+                        break;
+                    }
+                    picked[ind] = 1;
+                    for (int l = 1; l <= 5; ++l) {
+                        if (ind + l >= (int)n) break;
+                        if (abs((int)(pointColInd[ind + l] - pointColInd[ind + l - 1])) > 10) break;
+                        picked[ind + l] = 1;
+                    }
+                    for (int l = -1; l >= -5; --l) {
+                        if (ind + l < 0) break;
+                        if (abs((int)(pointColInd[ind + l] - pointColInd[ind + l + 1])) > 10) break;
+                        picked[ind + l] = 1;
+                    }
+                }
+            }
+            for (int k = sp; k <= ep; ++k) {                                    /* FE:197 */
+                int ind = sm[k].ind;
+                if (picked[ind] == 0 && curv[ind] < surfThreshold) {
+                    label[ind] = -1;
+                    picked[ind] = 1;
+                    for (int l = 1; l <= 5; ++l) {
+                        if (ind + l >= (int)n) break;
+                        if (abs((int)(pointColInd[ind + l] - pointColInd[ind + l - 1])) > 10) break;
+                        picked[ind + l] = 1;
+                    }
+                    for (int l = -1; l >= -5; --l) {
+                        if (ind + l < 0) break;
+                        if (abs((int)(pointColInd[ind + l] - pointColInd[ind + l + 1])) > 10) break;
+                        picked[ind + l] = 1;
+                    }
+                }
+            }
+            for (int k = sp; k <= ep; ++k)                                      /* FE:224: label by POSITION k */
+                if (label[k] <= 0) { memcpy(ring_in + 4 * n_ring, cloud_xyzi + 4 * (size_t)k, sizeof(float) * 4); ++n_ring; }
+        }
+        size_t n_ds = 0;                                                        /* FE:232-236 */
+        lo_voxel_grid(ring_in, n_ring, surfLeaf, ring_out, &n_ds);
+        memcpy(surf_xyzi + 4 * (*n_surf), ring_out, sizeof(float) * 4 * n_ds);
+        *n_surf += n_ds;
+    }
+    if (curvature_out) memcpy(curvature_out, curv, sizeof(float) * n);
+    if (picked_out) memcpy(picked_out, picked, sizeof(int32_t) * n);
+    if (label_out) memcpy(label_out, label, sizeof(int32_t) * n);
+    free(curv); free(picked); free(label); free(sm); free(ring_in); free(ring_out);
+    return 0;
+}
+
+/* =========================================================================
  * EXTENSION BEYOND THE REFERENCE -- point-to-line ("corner") residuals.
  *
  * BASELINE.json's north_star names `cornerOptimization`, but this reference (a liorf fork) has

@@ -196,6 +196,15 @@ void lo_transform_point_cloud(const float *in_xyzi, size_t n, const float pose[6
 /* pcl::VoxelGrid centroid filter (MO:1605-1611, MO:1581-1583); out has room for n points */
 int  lo_voxel_grid(const float *in_xyzi, size_t n, float leaf, float *out_xyzi, size_t *n_out);
 
+/* featureExtraction.cpp FE:103-238 */
+void lo_mark_occluded(const float *pointRange, const int32_t *pointColInd, size_t n, int32_t *picked);
+int lo_extract_features(const float *cloud_xyzi, size_t n, int n_scan,
+                        const int32_t *startRingIndex, const int32_t *endRingIndex,
+                        const int32_t *pointColInd, const float *pointRange,
+                        float edgeThreshold, float surfThreshold, float surfLeaf,
+                        float *corner_xyzi, size_t *n_corner, float *surf_xyzi, size_t *n_surf,
+                        float *curvature_out, int32_t *picked_out, int32_t *label_out);
+
 /* ---- EXTENSION beyond the reference: point-to-line residuals (upstream LIO-SAM
  * cornerOptimization; absent from this fork; parity unpinned) ---- */
 void lo_eigen3_sym(const float A[9], float evals[3], float evecs[9]);

@@ -105,6 +105,11 @@ class Oracle:
         L.lo_transform_point_cloud.argtypes = [_f32p, C.c_size_t, _f32p, _f32p, C.c_int]
         L.lo_voxel_grid.argtypes = [_f32p, C.c_size_t, C.c_float, _f32p, C.POINTER(C.c_size_t)]
         L.lo_eigen3_sym.argtypes = [_f32p, _f32p, _f32p]
+        L.lo_mark_occluded.argtypes = [_f32p, _i32p, C.c_size_t, _i32p]
+        L.lo_extract_features.argtypes = [_f32p, C.c_size_t, C.c_int, _i32p, _i32p, _i32p, _f32p, C.c_float, C.c_float,
+                                          C.c_float, _f32p, C.POINTER(C.c_size_t), _f32p, C.POINTER(C.c_size_t),
+                                          _f32p, _i32p, _i32p]
+        L.lo_extract_features.restype = C.c_int
         L.lo_corner_optimization.argtypes = [C.POINTER(S2MConfig), _f32p, _f32p, C.c_size_t, _f32p,
                                              C.c_size_t, C.c_void_p, _u8p, _f32p, _i32p]
         L.lo_scan2map_cs.argtypes = [C.POINTER(S2MConfig), _f32p, C.c_size_t, _f32p, C.c_size_t, _f32p, C.c_size_t,
@@ -306,3 +311,28 @@ class Oracle:
                                 cm.reshape(-1) if len(cm) else dummy, len(cm), ss.reshape(-1), len(ss),
                                 sm.reshape(-1), len(sm), pose, matP, deg, C.byref(res), corr_iter, a, b, c)
         return pose, res, matP.reshape(6, 6), corr
+
+    # ---- featureExtraction.cpp FE:103-238 ----
+    def mark_occluded(self, point_range, point_col):
+        r = np.ascontiguousarray(point_range, np.float32)
+        col = np.ascontiguousarray(point_col, np.int32)
+        picked = np.zeros(len(r), np.int32)
+        self.lib.lo_mark_occluded(r, col, len(r), picked)
+        return picked
+
+    def extract_features(self, cloud_xyzi, start_ring, end_ring, point_col, point_range,
+                         edge_threshold=1.0, surf_threshold=0.1, surf_leaf=0.2):
+        cloud = np.ascontiguousarray(cloud_xyzi, np.float32).reshape(-1, 4)
+        n = len(cloud)
+        sr = np.ascontiguousarray(start_ring, np.int32); er = np.ascontiguousarray(end_ring, np.int32)
+        col = np.ascontiguousarray(point_col, np.int32); rng = np.ascontiguousarray(point_range, np.float32)
+        corner = np.zeros((max(n, 1), 4), np.float32); surf = np.zeros((max(n, 1), 4), np.float32)
+        nc, ns = C.c_size_t(0), C.c_size_t(0)
+        curv = np.zeros(max(n, 1), np.float32); picked = np.zeros(max(n, 1), np.int32); label = np.zeros(max(n, 1), np.int32)
+        rc = self.lib.lo_extract_features(cloud.reshape(-1) if n else np.zeros(4, np.float32), n, len(sr), sr, er, col, rng,
+                                          edge_threshold, surf_threshold, surf_leaf, corner.reshape(-1), C.byref(nc),
+                                          surf.reshape(-1), C.byref(ns), curv, picked, label)
+        if rc != 0:
+            raise ValueError("ring index ranges outside [0, n-1]")
+        return {"corner": corner[:nc.value].copy(), "surface": surf[:ns.value].copy(),
+                "curvature": curv[:n], "picked": picked[:n], "label": label[:n]}
