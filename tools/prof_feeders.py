@@ -19,7 +19,10 @@ if mode == "gen":
         s = synth.cast_scan(boxes, kp, "hdl64", seed=1000 + k)
         ds = synth.voxel_downsample(s["xyz"], 0.4)
         clouds.append(np.concatenate([ds, np.zeros((len(ds), 1), np.float32)], 1)); lens.append(len(ds))
+    sc0 = synth.cast_scan(boxes, kfs[100], "hdl64", seed=1)
+    org = synth.organize_scan(sc0)
     np.savez(path, xyz=sc["xyz"], intensity=sc["intensity"], ring=sc["ring"], time=sc["time"], range=sc["range"],
+             org_cloud=org["cloud"], org_start=org["start_ring"], org_end=org["end_ring"], org_col=org["col"], org_range=org["range"],
              kf=np.concatenate(clouds), kf_lens=np.array(lens), kf_poses=kfs.astype(np.float32))
     print("generated", len(sc["xyz"]), "raw points,", sum(lens), "keyframe points")
 else:
@@ -54,3 +57,11 @@ else:
     for _ in range(reps):
         _, n_out, _ = store.assemble(ids, z["kf_poses"], 0.5, s2m=s2m, want_output=False)
     print(f"K6+K7 map assembly: {int(offs[-1])} -> {n_out} points + grid build, {1e3 * (time.perf_counter() - t) / reps:.3f} ms/call (resident keyframes)")
+    if "org_cloud" in z:
+        args = (z["org_cloud"], z["org_start"], z["org_end"], z["org_col"], z["org_range"])
+        pkg.extract_features(*args)
+        t = time.perf_counter()
+        for _ in range(reps):
+            f = pkg.extract_features(*args)
+        print(f"FE:67-77 smoothness + occlusion + feature selection + per-ring voxel 0.2 m: {len(z['org_cloud'])} points -> "
+              f"{len(f['corner'])} corner, {len(f['surface'])} surface, {1e3 * (time.perf_counter() - t) / reps:.3f} ms/call incl. H2D+D2H")
