@@ -264,7 +264,7 @@ int  lio_curvature(int32_t device_id, const float *range, size_t n, float *curva
  * array boundary instead of indexing pointColInd[-1]. */
 typedef struct lio_feature_config {
     int32_t N_SCAN;          /* UT:164 */
-    float   edgeThreshold;   /* UT:186, 1.0 in config/*.yaml */
+    float   edgeThreshold;   /* UT:186, 1.0 in the yaml configs */
     float   surfThreshold;   /* UT:187, 0.1 */
     float   surfLeafSize;    /* mappingSurfLeafSize FE:56 */
     int32_t device_id;

@@ -392,11 +392,26 @@ def pack_xyzirt(xyz, intensity, ring, time):
 
 
 # projectPointCloud + deskewPoint, IP:545-615
+_SCRATCH = {}
+
+
+def _scratch(name, shape, dtype=np.float32):
+    """Re-used host output buffer (like a node's member clouds).  A fresh np.zeros per call hands the HIP
+    runtime never-touched pages to pin for the D2H copy, which costs milliseconds and says nothing about
+    the library; results are copied out of the scratch before they are returned."""
+    need = int(np.prod(shape))
+    buf = _SCRATCH.get((name, np.dtype(dtype).str))
+    if buf is None or buf.size < need:
+        buf = np.zeros(max(need, 1), dtype)
+        _SCRATCH[(name, np.dtype(dtype).str)] = buf
+    return buf[:need].reshape(shape)
+
+
 def deskew(dcfg, records, t_cur, imu):
     cur, T, RX, RY, RZ = imu
     L = load_library()
     n = len(records)
-    out = np.zeros((n, 8), np.float32)     # pcl::PointXYZI, 32-byte stride
+    out = _scratch("deskew", (n, 8))       # pcl::PointXYZI, 32-byte stride
     n_out = C.c_size_t()
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     rec = np.ascontiguousarray(records)
@@ -443,8 +458,8 @@ def extract_features(cloud_xyzi, start_ring, end_ring, point_col, point_range, d
     er = np.ascontiguousarray(end_ring, np.int32)
     col = np.ascontiguousarray(point_col, np.int32)
     rng = np.ascontiguousarray(point_range, np.float32)
-    corner = np.zeros((120 * max(cfg.N_SCAN, 1), 8), np.float32)
-    surf = np.zeros((max(n, 1), 8), np.float32)
+    corner = _scratch("fe_corner", (120 * max(cfg.N_SCAN, 1), 8))
+    surf = _scratch("fe_surf", (max(n, 1), 8))
     curv = np.zeros(max(n, 1), np.float32)
     picked = np.zeros(max(n, 1), np.int32)
     label = np.zeros(max(n, 1), np.int32)
@@ -474,7 +489,7 @@ def _from_records(rec, n):
 # downsampleCurrentScan, MO:1605-1611 (pcl::VoxelGrid)
 def voxel_grid(xyzi, leaf, device_id=0):
     rec = _as_xyzi_records(xyzi)
-    out = np.zeros_like(rec)
+    out = _scratch("voxel", rec.shape)
     n_out = C.c_size_t()
     rc = _check(load_library().lio_voxel_grid(device_id, rec.ctypes.data, len(rec), 32, leaf, out.ctypes.data, 32,
                                               C.byref(n_out)), "lio_voxel_grid")
@@ -489,7 +504,7 @@ def assemble_map(clouds_xyzi, poses, leaf, s2m=None, device_id=0, want_output=Tr
     npts = (C.c_size_t * max(n, 1))(*[len(r) for r in recs])
     p = np.ascontiguousarray(poses, np.float32).reshape(n, 6)
     total = sum(len(r) for r in recs)
-    out = np.zeros((max(total, 1), 8), np.float32) if want_output else None
+    out = _scratch("assemble", (max(total, 1), 8)) if want_output else None
     n_out = C.c_size_t()
     rc = _check(load_library().lio_assemble_map(s2m.h if s2m is not None else None, device_id, n, ptrs, npts, 32,
                                                 _f32p(p), leaf, out.ctypes.data if want_output else None, 32,

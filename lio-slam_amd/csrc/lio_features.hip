@@ -129,20 +129,68 @@ struct FeatParams {
     int* status;            // != 0: a capacity limit was hit
 };
 
-// the suppression walk FE:178-193 / FE:210-221 on the ring window held in LDS
-__device__ static void feat_suppress(unsigned char* s_picked, const short* s_col, int ind, int w0, int n)
+// The suppression walk FE:178-193 / FE:210-221 on the ring window held in LDS, by one wave: lanes 0..4 test
+// the forward steps l = 1..5, lanes 8..12 the backward steps l = -1..-5; a walk marks every step before its
+// first "stop" (column gap > 10, or the end of the arrays).
+__device__ static void feat_suppress_wave(volatile unsigned char* s_picked, const short* s_col, int ind, int w0, int n, int lane)
 {
-    s_picked[ind - w0] = 1;
-    for (int l = 1; l <= 5; ++l) {
-        if (ind + l >= n) break;
-        if (abs((int)s_col[ind + l - w0] - (int)s_col[ind + l - 1 - w0]) > 10) break;
-        s_picked[ind + l - w0] = 1;
+    const bool fwd = lane < 5, bwd = lane >= 8 && lane < 13;
+    const int l = fwd ? lane + 1 : -(lane - 7);
+    bool stop = false;
+    if (fwd) stop = (ind + l >= n) || abs((int)s_col[min(ind + l, n - 1) - w0] - (int)s_col[ind + l - 1 - w0]) > 10;
+    if (bwd) stop = (ind + l < 0) || abs((int)s_col[max(ind + l, 0) - w0] - (int)s_col[ind + l + 1 - w0]) > 10;
+    const unsigned long long sm = __ballot(stop);
+    const unsigned fm = (unsigned)(sm & 0x1f), bm = (unsigned)((sm >> 8) & 0x1f);
+    const int ff = fm ? __builtin_ctz(fm) : 5, bf = bm ? __builtin_ctz(bm) : 5;   // first stopping step (0-based)
+    if (lane == 0) s_picked[ind - w0] = 1;
+    if (fwd && lane < ff) s_picked[ind + l - w0] = 1;
+    if (bwd && lane - 8 < bf) s_picked[ind + l - w0] = 1;
+}
+
+// One greedy pass of a sector, executed by one wave in chunks of 64 visit positions.  Visit order:
+// corner pass = element ep, then the sorted range descending (FE:165 `k = ep .. sp`); surface pass = the
+// sorted range ascending, then element ep (FE:197).  Within a chunk every lane holds one element; the wave
+// repeatedly takes the first lane whose element is still unpicked and passes the threshold -- exactly the
+// element the sequential loop would reach next -- applies the pick, and re-reads the flags.
+template <bool CORNER>
+__device__ static int feat_greedy_pass(const u64* s_sort, unsigned char* s_picked_, signed char* s_label, const float* s_curv,
+                                       const short* s_col, int sp, int ep, int w0, int n, float thr,
+                                       int* corner_idx, int n_corner)
+{
+    volatile unsigned char* s_picked = s_picked_;
+    const int lane = threadIdx.x & 63;
+    const int m = ep - sp;                                   // sorted elements; visits = m + 1
+    int largestPickedNum = 0;
+    for (int q0 = 0; q0 <= m; q0 += 64) {
+        const int q = q0 + lane;
+        const bool valid = q <= m;
+        int ind = ep;
+        if (valid) {
+            if (CORNER) { if (q > 0) ind = (int)(unsigned)(s_sort[m - q] & 0xffffffffu); }
+            else        { if (q < m) ind = (int)(unsigned)(s_sort[q] & 0xffffffffu); }
+        }
+        const float cv = s_curv[ind - w0];
+        const bool cand = valid && (CORNER ? cv > thr : cv < thr);
+        int cursor = 0;
+        for (;;) {
+            const bool live = cand && lane >= cursor && s_picked[ind - w0] == 0;
+            const unsigned long long mask = __ballot(live);
+            if (!mask) break;
+            const int j = __builtin_ctzll(mask);
+            const int pick = __shfl(ind, j);
+            if (CORNER) {
+                ++largestPickedNum;                                          // FE:169-176
+                if (largestPickedNum > 20) return n_corner;
+                if (lane == 0) { s_label[pick - w0] = 1; corner_idx[n_corner] = pick; }
+                ++n_corner;
+            } else {
+                if (lane == 0) s_label[pick - w0] = -1;                      // FE:202
+            }
+            feat_suppress_wave(s_picked, s_col, pick, w0, n, lane);
+            cursor = j + 1;
+        }
     }
-    for (int l = -1; l >= -5; --l) {
-        if (ind + l < 0) break;
-        if (abs((int)s_col[ind + l - w0] - (int)s_col[ind + l + 1 - w0]) > 10) break;
-        s_picked[ind + l - w0] = 1;
-    }
+    return n_corner;
 }
 
 __global__ __launch_bounds__(FEAT_BLOCK) void k_feat_ring(FeatParams P)
@@ -189,30 +237,13 @@ __global__ __launch_bounds__(FEAT_BLOCK) void k_feat_ring(FeatParams P)
             s_sort[t] = t < m ? (((u64)__float_as_uint(s_curv[sp + t - w0])) << 32) | (unsigned)(sp + t) : ~0ull;
         __syncthreads();
         feat_bitonic_sort(s_sort, mp);
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < 64) {                                             // wave 0; LDS ops of one wave retire in order
             int n_corner = s_n_corner;
-            int largestPickedNum = 0;
-            for (int k = ep; k >= sp; --k) {                                // FE:165
-                const int ind = (k == ep) ? ep : (int)(unsigned)(s_sort[k - sp] & 0xffffffffu);
-                if (s_picked[ind - w0] == 0 && s_curv[ind - w0] > P.edge_thr) {
-                    ++largestPickedNum;
-                    if (largestPickedNum <= 20) {
-                        s_label[ind - w0] = 1;
-                        P.corner_idx[ring * FEAT_MAX_PICK + n_corner++] = ind;
-                    } else {
-                        break;
-                    }
-                    feat_suppress(s_picked, s_col, ind, w0, P.n);
-                }
-            }
-            s_n_corner = n_corner;
-            for (int k = sp; k <= ep; ++k) {                                // FE:197
-                const int ind = (k == ep) ? ep : (int)(unsigned)(s_sort[k - sp] & 0xffffffffu);
-                if (s_picked[ind - w0] == 0 && s_curv[ind - w0] < P.surf_thr) {
-                    s_label[ind - w0] = -1;
-                    feat_suppress(s_picked, s_col, ind, w0, P.n);
-                }
-            }
+            n_corner = feat_greedy_pass<true>(s_sort, s_picked, s_label, s_curv, s_col, sp, ep, w0, P.n, P.edge_thr,
+                                              P.corner_idx + ring * FEAT_MAX_PICK, n_corner);     // FE:165-195
+            if (threadIdx.x == 0) s_n_corner = n_corner;
+            feat_greedy_pass<false>(s_sort, s_picked, s_label, s_curv, s_col, sp, ep, w0, P.n, P.surf_thr,
+                                    nullptr, 0);                                                   // FE:197-222
         }
         __syncthreads();
         if (first_valid < 0) first_valid = sp;
