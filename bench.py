@@ -345,6 +345,19 @@ def main():
                                    "keyframes": len(kc), "points_in": int(sum(len(c) for c in kc)), "points_out": int(n_asm)}
             store.close()
             asm.close()
+        if keyframes and not sharded:
+            # the step after the deskew: FeatureExtraction::laserCloudInfoHandler FE:67-77 for one
+            # organised 64x1800 sweep, host arrays in, corner/surface clouds out
+            boxes = synth.make_scene(synth.BASE_SEED, length=max(60.0, float(args.keyframes) + 20.0))
+            org = synth.organize_scan(synth.cast_scan(boxes, poses_true[0], args.sensor, seed=77, device=f"cuda:{local_rank}"))
+            fe_args = (org["cloud"], org["start_ring"], org["end_ring"], org["col"], org["range"])
+            fe = pkg.extract_features(*fe_args, device_id=local_rank)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fe = pkg.extract_features(*fe_args, device_id=local_rank)
+            out["feature_extraction"] = {"ms_per_sweep_incl_h2d_d2h": 1e3 * (time.perf_counter() - t0) / 5,
+                                         "points": int(len(org["cloud"])), "corner": int(len(fe["corner"])),
+                                         "surface": int(len(fe["surface"]))}
         if args.latency and not sharded:
             lat = pkg.ScanToMap(device_id=local_rank)
             lat.set_map(map_xyz)
