@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--graph", type=int, default=12, help="replay a hipGraph of this many GN iterations per launch unit (0 = eager launches)")
     ap.add_argument("--shard", choices=["map", "scan"], default="scan",
                     help="N>1: map = slabs of the map + halo, owner-computes (north_star); scan = map replicated, workgroups of every scan dealt round-robin")
+    ap.add_argument("--nncache", type=int, default=1, help="1 = bound each point's search by its previous neighbours (exact)")
     ap.add_argument("--lawnmower", action="store_true", help="keyframes on a lawn-mower path inside a 50 m radius (configs[3])")
     args = ap.parse_args()
 
@@ -209,7 +210,7 @@ def main():
 
     # -------------------------------------------------------------- engine
     kcfg = dict(device_id=local_rank, profile=1, use_graph=1 if args.graph else 0, graph_iters=max(args.graph, 1), lookahead=args.lookahead, kernel_variant=args.variant,
-                use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch)
+                use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch, nn_cache=args.nncache)
     if sharded:
         runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2, **kcfg)
         runner.upload(scans)
@@ -302,7 +303,7 @@ def main():
             (f"map sharded x{world} (slabs + halo, owner-computes)" if args.shard == "map" else
              f"map replicated, scan workgroups dealt over {world} ranks") + " + RCCL all-reduce of JtJ/Jtr per GN iteration",
             "kernel": {"points_per_thread": int(args.variant), "lds_staging": int(args.lds),
-                       "tile_sorted_scans": int(args.sort), "cell_div": int(args.celldiv)},
+                       "nn_cache": args.nncache, "tile_sorted_scans": int(args.sort), "cell_div": int(args.celldiv)},
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

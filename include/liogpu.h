@@ -82,6 +82,9 @@ typedef struct lio_s2m_config {
     int32_t graph_iters;     /* iterations per captured chunk (default 4)                   */
     int32_t sort_batch;      /* 1 (default) = order the workgroups of a batch by the scans'
                                 positions (L2 locality only; results are unaffected)       */
+    int32_t nn_cache;        /* 1 (default) = from the second GN iteration on, bound each point's
+                                search by the distances to its previous 5 neighbours (exact:
+                                the candidate run shrinks, the result does not change)      */
 } lio_s2m_config;
 
 /* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in

@@ -32,7 +32,7 @@ class S2MConfig(C.Structure):
         ("max_scan_pts", C.c_int32), ("record_corr_iter", C.c_int32), ("kernel_variant", C.c_int32),
         ("profile", C.c_int32), ("lookahead", C.c_int32), ("use_lds", C.c_int32), ("sort_scan", C.c_int32),
         ("cell_div", C.c_int32), ("xcd_remap", C.c_int32), ("tile_size", C.c_float),
-        ("use_graph", C.c_int32), ("graph_iters", C.c_int32), ("sort_batch", C.c_int32),
+        ("use_graph", C.c_int32), ("graph_iters", C.c_int32), ("sort_batch", C.c_int32), ("nn_cache", C.c_int32),
     ]
 
 

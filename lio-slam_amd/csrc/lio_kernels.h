@@ -28,6 +28,8 @@ struct LioIterParams {
     unsigned char* rec_flag;       // optional correspondence record (iteration c.record_iter)
     float* rec_coeff;
     int* rec_nn;
+    int* nn_cache;                 // [5][total_pts] neighbours of the previous iteration (-1 in row 0: none), or null
+    int total_pts;
     long long* stamps;             // diagnostic phase clock: [block][wave][8] cycle counters, or null
 };
 

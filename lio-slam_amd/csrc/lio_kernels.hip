@@ -535,9 +535,11 @@ LIO_DEV void lio_knn_pair(const float4& a, const float4& b, lio_f2 qx, lio_f2 qy
 }
 
 LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
-                            int cx, int cy, int cz, LioTop5& top)
+                            int cx, int cy, int cz, int xlo, int xhi, LioTop5& top)
 {
-    const int x0 = max(cx - g.k, 0), x1 = min(cx + g.k, g.nx - 1);
+    // [xlo, xhi]: x-cells that can hold a point closer than the current bound (the whole +-k range
+    // unless the previous iteration's neighbours gave a tighter one, see "neighbour cache" below)
+    const int x0 = max(max(cx - g.k, 0), xlo), x1 = min(min(cx + g.k, g.nx - 1), xhi);
     if (x0 > x1) return;
     const int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nx;
     const unsigned beg = (unsigned)P.nbr_start[row + x0] & ~3u;
@@ -685,6 +687,7 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
     const int n_pts = CORNER ? st->c_n_pts : st->n_pts;
     const int base = CORNER ? st->c_offset : st->offset;
     const bool record = (P.rec_flag != nullptr) && (st->iter == P.c.record_iter);
+    const bool use_cache = (P.nn_cache != nullptr) && !STAGE && st->iter > 0;   // iteration 0 has nothing to re-use
     const LioGrid g = P.grid;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -817,14 +820,41 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
 #pragma unroll 1
     for (int pp = 0; pp < PPT; ++pp) {
         // ---- exact 5-NN over the 27-cell neighbourhood (MO:1631) ----
-        const double sentinel = lio_make_key(P.c.max_sq_dist, LIO_IDX_MASK);
+        // Neighbour cache (speed only).  The 5 neighbours found in the previous iteration are still map
+        // points: the largest of their squared distances to the moved query, R2, bounds the new 5th
+        // distance from above, so every member of the new 5-NN set lies within sqrt(R2) of the query --
+        // in particular inside the x-cells [cell(qx - R), cell(qx + R)] -- and candidates beyond R2 can be
+        // turned away by the sentinel.  Typically R ~ 0.5 m against the 1 m gate: half the candidate run.
+        float bound2 = P.c.max_sq_dist;
+        int xlo = -0x7fffffff, xhi = 0x7fffffff;
+        const int ci = base + bd.first + pp * LIO_BLOCK + (int)threadIdx.x;   // slot in the batch SoA
+        if (use_cache && act[pp]) {
+            const int n0 = P.nn_cache[ci];
+            if (n0 >= 0) {
+                float r2 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int nj = j == 0 ? n0 : P.nn_cache[(size_t)j * P.total_pts + ci];
+                    const float4 mp = P.map_xyz4[nj];
+                    r2 = fmaxf(r2, lio_sqdist(mp.x, mp.y, mp.z, qx[pp], qy[pp], qz[pp]));
+                }
+                if (r2 < bound2) {
+                    bound2 = r2;
+                    const float R = sqrtf(r2) * 1.0001f + 1e-6f;          // rounded up
+                    xlo = lio_cell_coord(qx[pp] - R, g.ox, g.inv_cell, g.nx);
+                    xhi = lio_cell_coord(qx[pp] + R, g.ox, g.inv_cell, g.nx);
+                }
+            }
+        }
+        // (d2 == bound2 with any real index sorts below the sentinel, so ties at the bound are kept)
+        const double sentinel = lio_make_key(bound2, LIO_IDX_MASK);
         LioTop5 top = { sentinel, sentinel, sentinel, sentinel, sentinel };
         if (act[pp]) {
             if (STAGE && staged)
                 lio_knn_lds(s_pts, s_cell, rxn1, ryn, rx0, ry0, rz0, ry1, rz1, g.nx,
                             qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], top);
             else
-                lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], top);
+                lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], xlo, xhi, top);
         }
         // gate MO:1641: pointSearchSqDis[4] < 1.0
         const bool ok = act[pp] && (lio_key_d2(top.k4) < (double)P.c.max_sq_dist);
@@ -832,6 +862,13 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
 
         int nn[5] = { lio_key_idx(top.k0), lio_key_idx(top.k1), lio_key_idx(top.k2),
                       lio_key_idx(top.k3), lio_key_idx(top.k4) };
+        if (P.nn_cache && inr[pp]) {                                  // for the next iteration (-1: nothing to re-use)
+            P.nn_cache[ci] = ok ? nn[0] : -1;
+            if (ok) {
+#pragma unroll
+                for (int j = 1; j < 5; ++j) P.nn_cache[(size_t)j * P.total_pts + ci] = nn[j];
+            }
+        }
         float cxx = 0.0f, cyy = 0.0f, czz = 0.0f, cww = 0.0f;
         bool accept = false;
         if (ok) {

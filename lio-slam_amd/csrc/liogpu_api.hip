@@ -94,6 +94,7 @@ struct lio_s2m_handle {
     int* d_tmp_idx = nullptr; size_t cap_tmp_idx = 0;
     int* d_perm = nullptr; size_t cap_perm = 0;
     bool sorted = false;
+    int* d_nn_cache = nullptr; size_t cap_nn_cache = 0;   // [5][total_pts] neighbours of the previous GN iteration
     long long* d_stamps = nullptr; size_t cap_stamps = 0;
     // hipGraph-captured chunk of GN iterations (cfg.use_graph)
     hipGraph_t graph = nullptr;
@@ -168,6 +169,7 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->sort_batch = 1;
     c->graph_iters = 4;
     c->sort_scan = 1;
+    c->nn_cache = 1;
 }
 
 static void lio_fill_consts(lio_s2m_handle* h)
@@ -226,7 +228,8 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_cell_start, h->d_tile_sums, h->d_bbox, h->d_stage, h->d_sx, h->d_sy, h->d_sz,
                      h->d_state, h->d_poses, h->d_blocks, h->d_partials, h->d_arrive, h->d_rec_flag,
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
-                     h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts };
+                     h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
+                     h->d_nn_cache };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) {
         for (int i = 0; i < LIO_MAX_ITERS; ++i) {
@@ -433,6 +436,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     HIPCHK(lio_grow(&h->d_state, &h->cap_state, (size_t)n_scans));
     HIPCHK(lio_grow(&h->d_poses, &h->cap_poses, (size_t)n_scans * 6));
     HIPCHK(lio_grow(&h->d_arrive, &h->cap_arrive, (size_t)n_scans));
+    if (h->cfg.nn_cache && !h->cfg.use_lds) HIPCHK(lio_grow(&h->d_nn_cache, &h->cap_nn_cache, tt * 5));
 
     // launch geometry: one workgroup = LIO_BLOCK * ppt consecutive points of one scan
     int ppt = h->cfg.kernel_variant;
@@ -721,6 +725,8 @@ static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_ou
     P.rec_coeff = rec ? h->d_rec_coeff : nullptr;
     P.rec_nn = rec ? h->d_rec_nn : nullptr;
     P.stamps = (h->cfg.profile == 2) ? h->d_stamps : nullptr;
+    P.nn_cache = (h->cfg.nn_cache && !h->cfg.use_lds) ? h->d_nn_cache : nullptr;
+    P.total_pts = (int)h->total_pts;
 }
 
 // Arguments of the corner launch: the child's map, grid, edge points and workgroup list; everything
@@ -754,6 +760,12 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->c, h->d_active, h->stream);
+    // neighbour cache: iteration 0 never reads it and rewrites the entry of every point it processes; entries
+    // of points it does not process (owned by another rank) could date from an earlier map -> drop them
+    if (h->cfg.nn_cache && !h->cfg.use_lds && h->d_nn_cache && h->shard.axis >= 0)
+        HIPCHK(hipMemsetAsync(h->d_nn_cache, 0xff, (h->total_pts ? h->total_pts : 1) * sizeof(int), h->stream));
+    if (h->corner_active && h->corner->d_nn_cache && h->shard.axis >= 0)
+        HIPCHK(hipMemsetAsync(h->corner->d_nn_cache, 0xff, (h->corner->total_pts ? h->corner->total_pts : 1) * sizeof(int), h->stream));
     h->launches_this_run = 0;
     h->units_this_run = 0;
     h->unit_iters = 1;

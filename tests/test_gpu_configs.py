@@ -87,3 +87,27 @@ def test_config5_batched_properties(pkg, vlp16_50kf, synth):
     assert max(r.iters for r in res2) <= 3
     assert np.abs(poses2[:, 3:] - poses[:, 3:]).max() < 2e-3 and np.abs(poses2[:, :3] - poses[:, :3]).max() < 2e-4
     one.close(); s2m.close()
+
+
+def test_neighbour_cache_is_exact(pkg, oracle, small_case):
+    """cfg.nn_cache narrows the candidate run from the second iteration on; nothing observable may change:
+    every iteration's pose, correspondence count and the recorded association of a late iteration."""
+    import numpy as np
+    q = small_case["queries"][0]
+    outs = []
+    for nn_cache in (0, 1):
+        s2m = pkg.ScanToMap(nn_cache=nn_cache, record_corr_iter=3, force_all_iters=1, max_iters=8)
+        s2m.set_map(small_case["map"])
+        pose, res, rc = s2m.scan2MapOptimization(q["scan"], q["pose_init"])
+        outs.append((pose, np.array(res.pose_iter, np.float32), list(res.n_corr_iter), s2m.get_correspondences(0),
+                     np.array(res.AtA, np.float32)))
+        s2m.close()
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    for x, y in zip(a[3], b[3]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a[4], b[4])
+    cfg = oracle.default_config(knn_mode=1, n_threads=8, force_all_iters=1, max_iters=8)
+    po, ro, _, corr = oracle.scan2map(cfg, q["scan"], small_case["map"], q["pose_init"], corr_iter=3)
+    assert np.array_equal(b[3][0], corr[0]) and np.array_equal(b[3][2], corr[2])
+    assert list(ro.n_corr_iter)[:8] == b[2][:8]
