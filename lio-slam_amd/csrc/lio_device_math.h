@@ -443,6 +443,116 @@ __device__ static void lio_eigen6_sym(float* A, float* W, float* V, int* indR, i
     }
 }
 
+// The same decomposition executed by one whole wave (the serial version costs ~240 k cycles of dependent
+// LDS round trips and sits at the very end of the first launch of every registration).  Every
+// floating-point operation and every comparison is the one the serial code performs; only independent
+// ones run side by side:
+//   pivot     lanes 0-4 hold the row candidates |A[i][indR[i]]|, lanes 5-9 the column candidates
+//             |A[indC[i]][i]| in the order the serial scan visits them; the first lane holding the maximum
+//             is the serial scan's strict-`<` winner;
+//   rotation  lanes 0-5 rotate the (up to four) off-diagonal pairs, lanes 8-13 the six eigenvector pairs,
+//             lane 6 updates the pivot and the two diagonal entries;
+//   trackers  lanes 0-3 recompute indR[k], indC[k], indR[l], indC[l].
+// All lanes of the wave must call it; A, W, V, indR, indC are in LDS.
+#define LIO_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+__device__ static void lio_eigen6_sym_wave(float* A, float* W, float* V, int* indR, int* indC, int lane)
+{
+    const float eps = FLT_EPSILON;
+    if (lane < 36) V[lane] = (lane / 6 == lane % 6) ? 1.0f : 0.0f;
+    if (lane < 6) W[lane] = A[lane * 7];
+    if (lane < 5) {                                          // indR[k], k = lane
+        int m = lane + 1;
+        float mv = fabsf(A[lane * 6 + m]);
+        for (int i = lane + 2; i < 6; ++i) { const float val = fabsf(A[lane * 6 + i]); if (mv < val) { mv = val; m = i; } }
+        indR[lane] = m;
+    } else if (lane >= 9 && lane < 14) {                     // indC[k], k = lane - 8 in 1..5
+        const int k = lane - 8;
+        int m = 0;
+        float mv = fabsf(A[k]);
+        for (int i = 1; i < k; ++i) { const float val = fabsf(A[i * 6 + k]); if (mv < val) { mv = val; m = i; } }
+        indC[k] = m;
+    }
+    LIO_LDS_FENCE();
+    for (int iters = 0; iters < 6 * 6 * 30; ++iters) {
+        float v = -1.0f;
+        int ck = 0, cl = 0;
+        if (lane < 5) { ck = lane; cl = indR[lane]; v = fabsf(A[ck * 6 + cl]); }
+        else if (lane < 10) { cl = lane - 4; ck = indC[cl]; v = fabsf(A[ck * 6 + cl]); }
+        float mx = v;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        const unsigned long long win = __ballot(lane < 10 && v == mx) & 0x3ffull;
+        const int j = win ? __builtin_ctzll(win) : 0;
+        const int k = __shfl(ck, j), l = __shfl(cl, j);
+        const float p = A[k * 6 + l];
+        if (fabsf(p) <= eps) break;                          // wave-uniform
+        const float wk = W[k], wl = W[l];
+        const float y = (float)((wl - wk) * 0.5);
+        float t = fabsf(y) + lio_cv_hypot(p, y);
+        float s = lio_cv_hypot(p, t);
+        const float c = t / s;
+        s = p / s; t = (p / t) * p;
+        if (y < 0) { s = -s; t = -t; }
+        LIO_LDS_FENCE();                                     // every lane has read before anyone writes
+        if (lane < 6) {
+            const int i = lane;
+            if (i != k && i != l) {
+                const int a0i = i < k ? i * 6 + k : k * 6 + i, a1i = i < l ? i * 6 + l : l * 6 + i;
+                const float a0 = A[a0i], b0 = A[a1i];
+                A[a0i] = a0 * c - b0 * s; A[a1i] = a0 * s + b0 * c;
+            }
+        } else if (lane == 6) {
+            A[k * 6 + l] = 0;
+            W[k] = wk - t;
+            W[l] = wl + t;
+        } else if (lane >= 8 && lane < 14) {
+            const int i = lane - 8;
+            const float a0 = V[k * 6 + i], b0 = V[l * 6 + i];
+            V[k * 6 + i] = a0 * c - b0 * s; V[l * 6 + i] = a0 * s + b0 * c;
+        }
+        LIO_LDS_FENCE();
+        if (lane < 4) {
+            const int idx = lane < 2 ? k : l;
+            if ((lane & 1) == 0) {
+                if (idx < 5) {
+                    int m = idx + 1;
+                    float mv = fabsf(A[idx * 6 + m]);
+                    for (int i = idx + 2; i < 6; ++i) { const float val = fabsf(A[idx * 6 + i]); if (mv < val) { mv = val; m = i; } }
+                    indR[idx] = m;
+                }
+            } else if (idx > 0) {
+                int m = 0;
+                float mv = fabsf(A[idx]);
+                for (int i = 1; i < idx; ++i) { const float val = fabsf(A[i * 6 + idx]); if (mv < val) { mv = val; m = i; } }
+                indC[idx] = m;
+            }
+        }
+        LIO_LDS_FENCE();
+    }
+    if (lane == 0) {                                         // descending selection sort, eigenvectors are rows
+        for (int k = 0; k < 5; ++k) {
+            int m = k;
+            for (int i = k + 1; i < 6; ++i) if (W[m] < W[i]) m = i;
+            if (k != m) {
+                float t = W[m]; W[m] = W[k]; W[k] = t;
+                for (int i = 0; i < 6; ++i) { t = V[m * 6 + i]; V[m * 6 + i] = V[k * 6 + i]; V[k * 6 + i] = t; }
+            }
+        }
+    }
+    LIO_LDS_FENCE();
+}
+
+// C(6x6) = A(6x6) * B(6x6), one lane per output element; the same double accumulation over k as lio_gemm32f.
+__device__ static void lio_gemm6_wave(const float* A, const float* B, float* C, int lane)
+{
+    if (lane < 36) {
+        const int i = lane / 6, j = lane % 6;
+        double s = 0.0;
+        for (int p = 0; p < 6; ++p) s += (double)A[i * 6 + p] * (double)B[p * 6 + j];
+        C[lane] = (float)s;
+    }
+}
+
 // matV.inv(), MO:1807 (OpenCV hal::LU32f on [A | I], partial pivoting;
 // singular -> zero matrix).  A is destroyed, B receives the inverse.
 __device__ static int lio_inv6_lu(float* A, float* B)

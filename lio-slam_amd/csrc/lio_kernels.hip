@@ -410,60 +410,80 @@ LIO_DEV float lio_sqdist(float ax, float ay, float az, float bx, float by, float
 // the reduced sums onward, plus the loop control of scan2MapOptimization
 // MO:1848-1859.  One lane; `ws` is LDS (or any) working storage.
 __device__ static void lio_gn_step(LioScanState* st, const double* sums, const LioConsts& c, LioSolveWs* ws,
-                                   int* n_active)
+                                   int* n_active, int lane)
 {
+    // Called by ALL lanes of one wave.  Lane 0 carries the serial algorithm; the eigen-decomposition and the
+    // 6x6 product of the first iteration are spread over the wave (lio_eigen6_sym_wave, lio_gemm6_wave).
     const int it = st->iter;
     const int nc = (int)sums[LIO_SUM_NC];
+    const bool solve = nc >= c.min_corr;                       // MO:1721-1724 (wave-uniform)
     float pose[6];
-    for (int k = 0; k < 6; ++k) pose[k] = st->pose[k];
     bool conv = false;
-    st->n_corr_last = nc;
-    if (it < 32) st->n_corr_iter[it] = nc;
-
-    if (nc >= c.min_corr) {                                    // MO:1721-1724
-        int p = 0;
-        for (int a = 0; a < 6; ++a)
-            for (int b = a; b < 6; ++b) {
-                const float v = (float)sums[p++];
-                ws->AtA[a * 6 + b] = v; ws->AtA[b * 6 + a] = v;
-            }
-        for (int a = 0; a < 6; ++a) ws->AtB[a] = (float)sums[21 + a];
-        for (int k = 0; k < 36; ++k) { st->AtA[k] = ws->AtA[k]; ws->A[k] = ws->AtA[k]; }
-        for (int k = 0; k < 6; ++k) { st->AtB[k] = ws->AtB[k]; ws->X[k] = ws->AtB[k]; }
-
-        lio_solve6_qr(ws->A, ws->X, ws->vl, ws->hf);           // MO:1784
-
-        if (it == 0) {                                         // MO:1786-1808
-            for (int k = 0; k < 36; ++k) ws->A[k] = ws->AtA[k];
-            lio_eigen6_sym(ws->A, ws->W, ws->V, ws->indR, ws->indC);
-            for (int k = 0; k < 36; ++k) ws->V2[k] = ws->V[k];
-            int deg = 0;
-            for (int i = 5; i >= 0; --i) {
-                if (ws->W[i] < c.eig_thresh) {
-                    for (int j = 0; j < 6; ++j) ws->V2[i * 6 + j] = 0;
-                    deg = 1;
-                } else {
-                    break;
-                }
-            }
-            for (int k = 0; k < 36; ++k) ws->A[k] = ws->V[k];
-            lio_inv6_lu(ws->A, ws->B);
-            lio_gemm32f(ws->B, ws->V2, st->matP, 6, 6, 6);     // MO:1807
-            st->is_degenerate = deg;
-        }
-        if (st->is_degenerate) {                               // MO:1810-1815
-            for (int k = 0; k < 6; ++k) ws->X2[k] = ws->X[k];
-            lio_gemm32f(st->matP, ws->X2, ws->X, 6, 6, 1);
-        }
-        for (int k = 0; k < 6; ++k) pose[k] += ws->X[k];       // MO:1817-1822
-
-        // MO:1824-1831: rad2deg in float, squares/sqrt in double, stored as float
-        const double r0 = (double)(ws->X[0] * 57.29578f), r1 = (double)(ws->X[1] * 57.29578f), r2 = (double)(ws->X[2] * 57.29578f);
-        const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
-        const double t0 = (double)(ws->X[3] * 100), t1 = (double)(ws->X[4] * 100), t2 = (double)(ws->X[5] * 100);
-        const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);
-        conv = ((double)deltaR < c.conv_deg) && ((double)deltaT < c.conv_cm);   // MO:1833
+    if (lane == 0) {
+        for (int k = 0; k < 6; ++k) pose[k] = st->pose[k];
+        st->n_corr_last = nc;
+        if (it < 32) st->n_corr_iter[it] = nc;
     }
+
+    if (solve) {
+        int deg = 0;
+        if (lane == 0) {
+            deg = st->is_degenerate;
+            int p = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int b = a; b < 6; ++b) {
+                    const float v = (float)sums[p++];
+                    ws->AtA[a * 6 + b] = v; ws->AtA[b * 6 + a] = v;
+                }
+            for (int a = 0; a < 6; ++a) ws->AtB[a] = (float)sums[21 + a];
+            for (int k = 0; k < 36; ++k) { st->AtA[k] = ws->AtA[k]; ws->A[k] = ws->AtA[k]; }
+            for (int k = 0; k < 6; ++k) { st->AtB[k] = ws->AtB[k]; ws->X[k] = ws->AtB[k]; }
+
+            lio_solve6_qr(ws->A, ws->X, ws->vl, ws->hf);       // MO:1784
+        }
+        LIO_LDS_FENCE();
+        const float* matP = st->matP;
+        if (it == 0) {                                         // MO:1786-1808
+            if (lane < 36) ws->A[lane] = ws->AtA[lane];
+            LIO_LDS_FENCE();
+            lio_eigen6_sym_wave(ws->A, ws->W, ws->V, ws->indR, ws->indC, lane);   // cv::eigen, MO:1792
+            if (lane == 0) {
+                for (int k = 0; k < 36; ++k) ws->V2[k] = ws->V[k];
+                deg = 0;
+                for (int i = 5; i >= 0; --i) {
+                    if (ws->W[i] < c.eig_thresh) {
+                        for (int j = 0; j < 6; ++j) ws->V2[i * 6 + j] = 0;
+                        deg = 1;
+                    } else {
+                        break;
+                    }
+                }
+                for (int k = 0; k < 36; ++k) ws->A[k] = ws->V[k];
+                lio_inv6_lu(ws->A, ws->B);
+                st->is_degenerate = deg;
+            }
+            LIO_LDS_FENCE();
+            lio_gemm6_wave(ws->B, ws->V2, ws->A, lane);        // matP = matV.inv() * matV2, MO:1807
+            LIO_LDS_FENCE();
+            if (lane < 36) st->matP[lane] = ws->A[lane];
+            matP = ws->A;
+        }
+        if (lane == 0) {
+            if (deg) {                                         // MO:1810-1815
+                for (int k = 0; k < 6; ++k) ws->X2[k] = ws->X[k];
+                lio_gemm32f(matP, ws->X2, ws->X, 6, 6, 1);
+            }
+            for (int k = 0; k < 6; ++k) pose[k] += ws->X[k];   // MO:1817-1822
+
+            // MO:1824-1831: rad2deg in float, squares/sqrt in double, stored as float
+            const double r0 = (double)(ws->X[0] * 57.29578f), r1 = (double)(ws->X[1] * 57.29578f), r2 = (double)(ws->X[2] * 57.29578f);
+            const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+            const double t0 = (double)(ws->X[3] * 100), t1 = (double)(ws->X[4] * 100), t2 = (double)(ws->X[5] * 100);
+            const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+            conv = ((double)deltaR < c.conv_deg) && ((double)deltaT < c.conv_cm);   // MO:1833
+        }
+    }
+    if (lane != 0) return;
 
     for (int k = 0; k < 6; ++k) st->pose[k] = pose[k];
     if (it < 32) for (int k = 0; k < 6; ++k) st->pose_iter[it][k] = pose[k];
@@ -632,11 +652,9 @@ LIO_DEV void lio_arrive_and_finish(const LioIterParams& P, const LioBlockDesc& b
         s_sum[lane] = v;
         if (P.sums_out) P.sums_out[(size_t)bd.scan * LIO_SUMS + lane] = v;
     }
-    __builtin_amdgcn_wave_barrier();      // same wave: LDS ops retire in order
-    if (lane == 0) {
-        P.arrive[bd.scan] = 0;            // re-arm for the next launch
-        if (!P.sums_out) lio_gn_step(st, s_sum, P.c, s_ws, P.n_active);
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave: the sums are in LDS before anyone reads them
+    if (lane == 0) P.arrive[bd.scan] = 0;                  // re-arm for the next launch
+    if (!P.sums_out) lio_gn_step(st, s_sum, P.c, s_ws, P.n_active, lane);
 }
 
 // One thread = one scan point (x PPT points, strided by the workgroup size).
@@ -947,15 +965,15 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
 #undef LIO_STAMP
 }
 
-// Sharded mode: solve every scan from all-reduced sums (one lane per scan).
+// Sharded mode: solve every scan from all-reduced sums (one wave per scan).
 __global__ void k_s2m_apply(LioScanState* __restrict__ st, int n_scans, const double* __restrict__ sums, LioConsts c,
                             int* __restrict__ n_active)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.x;                                // one wave per scan
     if (s >= n_scans) return;
     if (st[s].done) return;
-    __shared__ LioSolveWs s_ws[64];
-    lio_gn_step(&st[s], sums + (size_t)s * LIO_SUMS, c, &s_ws[threadIdx.x], n_active);
+    __shared__ LioSolveWs s_ws;
+    lio_gn_step(&st[s], sums + (size_t)s * LIO_SUMS, c, &s_ws, n_active, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------ launch glue
@@ -1042,7 +1060,7 @@ void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stag
 void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
                       int* n_active, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_s2m_apply, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, sums, c, n_active);
+    hipLaunchKernelGGL(k_s2m_apply, dim3(n_scans), dim3(64), 0, s, st, n_scans, sums, c, n_active);
 }
 
 void lio_launch_scan_tile_sort(const void* stage, size_t stride, int total_pts,
