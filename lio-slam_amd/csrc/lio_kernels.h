@@ -28,8 +28,7 @@ struct LioIterParams {
     unsigned char* rec_flag;       // optional correspondence record (iteration c.record_iter)
     float* rec_coeff;
     int* rec_nn;
-    int* nn_cache;                 // [5][total_pts] neighbours of the previous iteration (-1 in row 0: none), or null
-    int total_pts;
+    float* d5_cache;               // [total_pts] squared 5th-neighbour distance of the previous iteration (-1: none), or null
     long long* stamps;             // diagnostic phase clock: [block][wave][8] cycle counters, or null
 };
 

@@ -506,6 +506,7 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
     st->status = (nc < c.min_corr) ? 2 : 0;
     if (done && n_active) atomicSub(n_active, 1);
     if (!done) {
+        for (int k = 0; k < 12; ++k) st->Tp[k] = st->T[k];         // (search bound of the next pass, see k_s2m_iterate)
         lio_pose_to_transform(pose, st->T, st->trig);              // MO:1613-1616 for the next pass
     }
 }
@@ -705,7 +706,10 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
     const int n_pts = CORNER ? st->c_n_pts : st->n_pts;
     const int base = CORNER ? st->c_offset : st->offset;
     const bool record = (P.rec_flag != nullptr) && (st->iter == P.c.record_iter);
-    const bool use_cache = (P.nn_cache != nullptr) && !STAGE && st->iter > 0;   // iteration 0 has nothing to re-use
+    const bool use_cache = (P.d5_cache != nullptr) && !STAGE && st->iter > 0;   // iteration 0 has nothing to re-use
+    float Tp[12];                                          // the transform of the previous iteration
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Tp[k] = use_cache ? st->Tp[k] : 0.0f;
     const LioGrid g = P.grid;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -838,27 +842,26 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
 #pragma unroll 1
     for (int pp = 0; pp < PPT; ++pp) {
         // ---- exact 5-NN over the 27-cell neighbourhood (MO:1631) ----
-        // Neighbour cache (speed only).  The 5 neighbours found in the previous iteration are still map
-        // points: the largest of their squared distances to the moved query, R2, bounds the new 5th
-        // distance from above, so every member of the new 5-NN set lies within sqrt(R2) of the query --
-        // in particular inside the x-cells [cell(qx - R), cell(qx + R)] -- and candidates beyond R2 can be
-        // turned away by the sentinel.  Typically R ~ 0.5 m against the 1 m gate: half the candidate run.
+        // Search bound from the previous iteration (speed only).  The 5 neighbours found last time lie within
+        // sqrt(d5_prev) of the point's previous position q_prev, hence within R = sqrt(d5_prev) + |q - q_prev| of
+        // its new position q: the new 5th distance cannot exceed R, every member of the new 5-NN set lies
+        // inside the x-cells [cell(qx - R), cell(qx + R)], and candidates beyond R^2 can be turned away by
+        // the sentinel.  R is rounded up by 1e-4 (fp32 rounding of the distances is 1e-7).  Typically
+        // R ~ 0.5 m against the 1 m gate: half the candidate run.  One float per point is kept.
         float bound2 = P.c.max_sq_dist;
         int xlo = -0x7fffffff, xhi = 0x7fffffff;
         const int ci = base + bd.first + pp * LIO_BLOCK + (int)threadIdx.x;   // slot in the batch SoA
         if (use_cache && act[pp]) {
-            const int n0 = P.nn_cache[ci];
-            if (n0 >= 0) {
-                float r2 = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    const int nj = j == 0 ? n0 : P.nn_cache[(size_t)j * P.total_pts + ci];
-                    const float4 mp = P.map_xyz4[nj];
-                    r2 = fmaxf(r2, lio_sqdist(mp.x, mp.y, mp.z, qx[pp], qy[pp], qz[pp]));
-                }
+            const float d5 = P.d5_cache[ci];
+            if (d5 >= 0.0f) {
+                const float ox = Tp[0] * px[pp] + Tp[1] * py[pp] + Tp[2]  * pz[pp] + Tp[3];
+                const float oy = Tp[4] * px[pp] + Tp[5] * py[pp] + Tp[6]  * pz[pp] + Tp[7];
+                const float oz = Tp[8] * px[pp] + Tp[9] * py[pp] + Tp[10] * pz[pp] + Tp[11];
+                const float mv = sqrtf(lio_sqdist(qx[pp], qy[pp], qz[pp], ox, oy, oz));
+                const float R = (sqrtf(d5) + mv) * 1.0001f + 1e-6f;
+                const float r2 = R * R * 1.0001f;
                 if (r2 < bound2) {
                     bound2 = r2;
-                    const float R = sqrtf(r2) * 1.0001f + 1e-6f;          // rounded up
                     xlo = lio_cell_coord(qx[pp] - R, g.ox, g.inv_cell, g.nx);
                     xhi = lio_cell_coord(qx[pp] + R, g.ox, g.inv_cell, g.nx);
                 }
@@ -880,13 +883,8 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
 
         int nn[5] = { lio_key_idx(top.k0), lio_key_idx(top.k1), lio_key_idx(top.k2),
                       lio_key_idx(top.k3), lio_key_idx(top.k4) };
-        if (P.nn_cache && inr[pp]) {                                  // for the next iteration (-1: nothing to re-use)
-            P.nn_cache[ci] = ok ? nn[0] : -1;
-            if (ok) {
-#pragma unroll
-                for (int j = 1; j < 5; ++j) P.nn_cache[(size_t)j * P.total_pts + ci] = nn[j];
-            }
-        }
+        if (P.d5_cache && inr[pp])                                    // for the next iteration (-1: nothing to re-use)
+            P.d5_cache[ci] = ok ? (float)lio_key_d2(top.k4) : -1.0f;
         float cxx = 0.0f, cyy = 0.0f, czz = 0.0f, cww = 0.0f;
         bool accept = false;
         if (ok) {

@@ -43,6 +43,7 @@ struct LioConsts {
 struct LioScanState {
     float pose[6];
     float T[12];
+    float Tp[12];            // T of the previous GN iteration
     float trig[6];
     int32_t n_pts;
     int32_t offset;          // first point of this scan in the batch SoA

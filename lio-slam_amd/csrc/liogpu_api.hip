@@ -94,7 +94,7 @@ struct lio_s2m_handle {
     int* d_tmp_idx = nullptr; size_t cap_tmp_idx = 0;
     int* d_perm = nullptr; size_t cap_perm = 0;
     bool sorted = false;
-    int* d_nn_cache = nullptr; size_t cap_nn_cache = 0;   // [5][total_pts] neighbours of the previous GN iteration
+    float* d_nn_cache = nullptr; size_t cap_nn_cache = 0;   // [total_pts] squared 5th-neighbour distance of the previous GN iteration
     long long* d_stamps = nullptr; size_t cap_stamps = 0;
     // hipGraph-captured chunk of GN iterations (cfg.use_graph)
     hipGraph_t graph = nullptr;
@@ -436,7 +436,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     HIPCHK(lio_grow(&h->d_state, &h->cap_state, (size_t)n_scans));
     HIPCHK(lio_grow(&h->d_poses, &h->cap_poses, (size_t)n_scans * 6));
     HIPCHK(lio_grow(&h->d_arrive, &h->cap_arrive, (size_t)n_scans));
-    if (h->cfg.nn_cache && !h->cfg.use_lds) HIPCHK(lio_grow(&h->d_nn_cache, &h->cap_nn_cache, tt * 5));
+    if (h->cfg.nn_cache && !h->cfg.use_lds) HIPCHK(lio_grow(&h->d_nn_cache, &h->cap_nn_cache, tt));
 
     // launch geometry: one workgroup = LIO_BLOCK * ppt consecutive points of one scan
     int ppt = h->cfg.kernel_variant;
@@ -725,8 +725,7 @@ static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_ou
     P.rec_coeff = rec ? h->d_rec_coeff : nullptr;
     P.rec_nn = rec ? h->d_rec_nn : nullptr;
     P.stamps = (h->cfg.profile == 2) ? h->d_stamps : nullptr;
-    P.nn_cache = (h->cfg.nn_cache && !h->cfg.use_lds) ? h->d_nn_cache : nullptr;
-    P.total_pts = (int)h->total_pts;
+    P.d5_cache = (h->cfg.nn_cache && !h->cfg.use_lds) ? h->d_nn_cache : nullptr;
 }
 
 // Arguments of the corner launch: the child's map, grid, edge points and workgroup list; everything
@@ -760,12 +759,13 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->c, h->d_active, h->stream);
-    // neighbour cache: iteration 0 never reads it and rewrites the entry of every point it processes; entries
-    // of points it does not process (owned by another rank) could date from an earlier map -> drop them
+    // search-bound cache: iteration 0 never reads it and rewrites the entry of every point it processes; entries
+    // of points it does not process (owned by another rank) could date from an earlier run -> drop them
+    // (0xff bytes = NaN, which fails the `>= 0` validity test like -1 does)
     if (h->cfg.nn_cache && !h->cfg.use_lds && h->d_nn_cache && h->shard.axis >= 0)
-        HIPCHK(hipMemsetAsync(h->d_nn_cache, 0xff, (h->total_pts ? h->total_pts : 1) * sizeof(int), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_nn_cache, 0xff, (h->total_pts ? h->total_pts : 1) * sizeof(float), h->stream));
     if (h->corner_active && h->corner->d_nn_cache && h->shard.axis >= 0)
-        HIPCHK(hipMemsetAsync(h->corner->d_nn_cache, 0xff, (h->corner->total_pts ? h->corner->total_pts : 1) * sizeof(int), h->stream));
+        HIPCHK(hipMemsetAsync(h->corner->d_nn_cache, 0xff, (h->corner->total_pts ? h->corner->total_pts : 1) * sizeof(float), h->stream));
     h->launches_this_run = 0;
     h->units_this_run = 0;
     h->unit_iters = 1;
