@@ -373,16 +373,15 @@ __global__ void k_scan_gather_sorted(const unsigned char* __restrict__ stage, si
 LIO_DEV double lio_dmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 LIO_DEV double lio_dmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-LIO_DEV double lio_make_key(float d2, int idx)
-{
-    const double d = (double)d2;                    // exact; low 29 mantissa bits are zero
-    return __hiloint2double(__double2hiint(d), __double2loint(d) | idx);
-}
-LIO_DEV double lio_key_d2(double key)               // the squared distance, exactly
-{
-    return __hiloint2double(__double2hiint(key), __double2loint(key) & ~LIO_IDX_MASK);
-}
-LIO_DEV int lio_key_idx(double key) { return __double2loint(key) & LIO_IDX_MASK; }
+// Key = the bit pattern (d2 as fp32 in the high word, map index in the low word) read as a double.
+// d2 >= 0 and never NaN (map records and queries are finite, see the `act` test), so the high word is a
+// non-negative fp32 pattern: its top 11 bits are never 0x7ff, i.e. the double is finite, and finite
+// non-negative doubles order exactly like their bit patterns -- numeric order of the keys =
+// lexicographic (d2, index).  No conversion instruction, no index-width limit; d2 = 0 gives a
+// denormal double, which v_min_f64 / v_max_f64 keep (fp64 denormals are on in the kernel's FP mode).
+LIO_DEV double lio_make_key(float d2, int idx) { return __hiloint2double(__float_as_int(d2), idx); }
+LIO_DEV float lio_key_d2(double key) { return __int_as_float(__double2hiint(key)); }   // the squared distance, exactly
+LIO_DEV int lio_key_idx(double key) { return __double2loint(key); }
 
 struct LioTop5 { double k0, k1, k2, k3, k4; };
 
@@ -737,7 +736,9 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
         cx[pp] = lio_cell_coord(qx[pp], g.ox, g.inv_cell, g.nx);
         cy[pp] = lio_cell_coord(qy[pp], g.oy, g.inv_cell, g.ny);
         cz[pp] = lio_cell_coord(qz[pp], g.oz, g.inv_cell, g.nz);
-        // a point whose 27 cells all lie outside the grid has no candidates at all
+        // a point whose 27 cells all lie outside the grid has no candidates at all; a non-finite point has no
+        // neighbours either (and would put NaN into the distance keys)
+        a = a && (fabsf(qx[pp]) <= 3.0e38f) && (fabsf(qy[pp]) <= 3.0e38f) && (fabsf(qz[pp]) <= 3.0e38f);
         a = a && cx[pp] >= -g.k && cx[pp] < g.nx + g.k && cy[pp] >= -g.k && cy[pp] < g.ny + g.k &&
             cz[pp] >= -g.k && cz[pp] < g.nz + g.k;
         act[pp] = a;
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
             }
         }
         // (d2 == bound2 with any real index sorts below the sentinel, so ties at the bound are kept)
-        const double sentinel = lio_make_key(bound2, LIO_IDX_MASK);
+        const double sentinel = lio_make_key(bound2, -1);                 // index 0xffffffff: above every real index
         LioTop5 top = { sentinel, sentinel, sentinel, sentinel, sentinel };
         if (act[pp]) {
             if (STAGE && staged)
@@ -878,13 +879,13 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
                 lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], xlo, xhi, top);
         }
         // gate MO:1641: pointSearchSqDis[4] < 1.0
-        const bool ok = act[pp] && (lio_key_d2(top.k4) < (double)P.c.max_sq_dist);
+        const bool ok = act[pp] && (lio_key_d2(top.k4) < P.c.max_sq_dist);
         if (pp == 0) LIO_STAMP(2);
 
         int nn[5] = { lio_key_idx(top.k0), lio_key_idx(top.k1), lio_key_idx(top.k2),
                       lio_key_idx(top.k3), lio_key_idx(top.k4) };
         if (P.d5_cache && inr[pp])                                    // for the next iteration (-1: nothing to re-use)
-            P.d5_cache[ci] = ok ? (float)lio_key_d2(top.k4) : -1.0f;
+            P.d5_cache[ci] = ok ? lio_key_d2(top.k4) : -1.0f;
         float cxx = 0.0f, cyy = 0.0f, czz = 0.0f, cww = 0.0f;
         bool accept = false;
         if (ok) {
