@@ -72,7 +72,8 @@ class FeatureConfig(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libliogpu.so")
+    # LIOGPU_LIB: A/B-test another build of the same library (kernel experiments); default = the in-tree build
+    return os.environ.get("LIOGPU_LIB") or os.path.join(_HERE, "libliogpu.so")
 
 
 def build_library(verbose=False):
