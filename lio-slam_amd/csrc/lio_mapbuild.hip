@@ -146,50 +146,135 @@ __global__ void k_vox_list(const int* __restrict__ start, const int* __restrict_
 // One wave per occupied voxel: order its points by input index (rank sort in LDS), stage them in
 // LDS, then one lane adds them up in that order in fp32 and divides by the count (PCL's
 // CentroidPoint accumulators).  Output position = rank of the voxel (ascending voxel index).
-#define LIO_VOX_CAP 512
+#define LIO_VOX_SMALL 32     // voxels with at most this many points are handled one per THREAD (k_vox_centroid_small)
+#define LIO_VOX_WAVE 128     // up to this many: one per wave (rank sort); larger ones go to k_vox_centroid_large
+#define LIO_VOX_LARGE 4096   // one per workgroup (bitonic sort in LDS); beyond that a slow exact fallback
 __global__ __launch_bounds__(256) void k_vox_centroid(const float4* __restrict__ p, const int* __restrict__ start,
                                                       const int* __restrict__ list, int n_out,
-                                                      const int* __restrict__ tmp, float4* __restrict__ out)
+                                                      const int* __restrict__ tmp, float4* __restrict__ out,
+                                                      int* __restrict__ large_list, int* __restrict__ n_large)
 {
-    __shared__ int s_idx[4][LIO_VOX_CAP];
-    __shared__ __attribute__((aligned(16))) float4 s_pt[4][LIO_VOX_CAP];
+    __shared__ int s_idx[4][LIO_VOX_WAVE];
+    __shared__ __attribute__((aligned(16))) float4 s_pt[4][LIO_VOX_WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int o = blockIdx.x * 4 + wave;
     if (o >= n_out) return;
     const int key = list[o];
     const int b = start[key], n = start[key + 1] - b;
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
-    if (n <= LIO_VOX_CAP) {
-        for (int j = lane; j < n; j += 64) s_idx[wave][j] = tmp[b + j];
-        __builtin_amdgcn_wave_barrier();
-        for (int j = lane; j < n; j += 64) {
-            const int v = s_idx[wave][j];
-            int r = 0;
-            for (int i = 0; i < n; ++i) r += (s_idx[wave][i] < v) ? 1 : 0;
-            s_pt[wave][r] = p[v];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0)
-            for (int j = 0; j < n; ++j) {
-                const float4 v = s_pt[wave][j];
-                sx += v.x; sy += v.y; sz += v.z; si += v.w;
-            }
-    } else {
-        // oversized voxel: repeatedly pick the smallest input index above the previous one
-        int prev = -1;
-        for (int j = 0; j < n; ++j) {
-            int best = 0x7fffffff;
-            for (int i = lane; i < n; i += 64) { const int v = tmp[b + i]; if (v > prev && v < best) best = v; }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off));
-            prev = best;
-            if (lane == 0) { const float4 v = p[best]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
-        }
+    if (n <= LIO_VOX_SMALL) return;                          // done by k_vox_centroid_small
+    if (n > LIO_VOX_WAVE) {                                  // queue for k_vox_centroid_large
+        if (lane == 0) large_list[atomicAdd(n_large, 1)] = o;
+        return;
     }
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+    for (int j = lane; j < n; j += 64) s_idx[wave][j] = tmp[b + j];
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < n; j += 64) {
+        const int v = s_idx[wave][j];
+        int r = 0;
+        for (int i = 0; i < n; ++i) r += (s_idx[wave][i] < v) ? 1 : 0;
+        s_pt[wave][r] = p[v];
+    }
+    __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
+        for (int j = 0; j < n; ++j) {
+            const float4 v = s_pt[wave][j];
+            sx += v.x; sy += v.y; sz += v.z; si += v.w;
+        }
         const float cnt = (float)n;
         out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
     }
+}
+
+// Crowded voxels (the rings next to the sensor put hundreds of returns into one 0.4 m voxel): one workgroup
+// per voxel, taken from the queue filled by k_vox_centroid.  Point indices are sorted with a bitonic network
+// in LDS, the points gathered in that order, and one lane adds them up (fp32 addition order is part of
+// the contract).  The queue order is arbitrary; every voxel writes its own output slot.
+__global__ __launch_bounds__(256) void k_vox_centroid_large(const float4* __restrict__ p, const int* __restrict__ start,
+                                                            const int* __restrict__ list, const int* __restrict__ tmp,
+                                                            float4* __restrict__ out, const int* __restrict__ large_list,
+                                                            const int* __restrict__ n_large)
+{
+    __shared__ int s_idx[LIO_VOX_LARGE];
+    __shared__ __attribute__((aligned(16))) float4 s_pt[1024];
+    const int total = *n_large;
+    for (int q = blockIdx.x; q < total; q += gridDim.x) {
+        const int o = large_list[q];
+        const int key = list[o];
+        const int b = start[key], n = start[key + 1] - b;
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+        if (n <= LIO_VOX_LARGE) {
+            int np = 2;
+            while (np < n) np <<= 1;
+            for (int j = threadIdx.x; j < np; j += 256) s_idx[j] = j < n ? tmp[b + j] : 0x7fffffff;
+            __syncthreads();
+            for (int k = 2; k <= np; k <<= 1)
+                for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                    for (int t = threadIdx.x; t < (np >> 1); t += 256) {
+                        const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), pr = i | jj;
+                        const bool up = (i & k) == 0;
+                        const int x = s_idx[i], y = s_idx[pr];
+                        if ((x > y) == up) { s_idx[i] = y; s_idx[pr] = x; }
+                    }
+                    __syncthreads();
+                }
+            for (int c0 = 0; c0 < n; c0 += 1024) {           // gather a chunk in sorted order, then add it up
+                const int m = min(1024, n - c0);
+                for (int j = threadIdx.x; j < m; j += 256) s_pt[j] = p[s_idx[c0 + j]];
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    for (int j = 0; j < m; ++j) { const float4 v = s_pt[j]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
+                __syncthreads();
+            }
+        } else if (threadIdx.x < 64) {
+            // more than 4096 points in one voxel: repeatedly pick the smallest input index above the previous one
+            const int lane = threadIdx.x;
+            int prev = -1;
+            for (int j = 0; j < n; ++j) {
+                int best = 0x7fffffff;
+                for (int i = lane; i < n; i += 64) { const int v = tmp[b + i]; if (v > prev && v < best) best = v; }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off));
+                prev = best;
+                if (lane == 0) { const float4 v = p[best]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
+            }
+        }
+        if (threadIdx.x == 0) {
+            const float cnt = (float)n;
+            out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+        }
+        __syncthreads();
+    }
+}
+
+// The common case -- a handful of points per voxel -- one thread per voxel: insertion-sort the point indices
+// in a private LDS slice (stride 33: conflict-free), then add the points up in that order.  A wave per voxel
+// spends its time on launch and latency: 67 k voxels of ~19 points took 0.4 ms that way, 64 voxels per wave
+// keep thousands of gathers in flight instead.
+__global__ __launch_bounds__(256) void k_vox_centroid_small(const float4* __restrict__ p, const int* __restrict__ start,
+                                                            const int* __restrict__ list, int n_out,
+                                                            const int* __restrict__ tmp, float4* __restrict__ out)
+{
+    __shared__ int s_idx[256 * (LIO_VOX_SMALL + 1)];
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    const int key = list[o];
+    const int b = start[key], n = start[key + 1] - b;
+    if (n > LIO_VOX_SMALL) return;                           // done by k_vox_centroid (one wave per voxel)
+    int* s = s_idx + threadIdx.x * (LIO_VOX_SMALL + 1);
+    for (int j = 0; j < n; ++j) {                            // ascending input index
+        const int v = tmp[b + j];
+        int i = j - 1;
+        while (i >= 0 && s[i] > v) { s[i + 1] = s[i]; --i; }
+        s[i + 1] = v;
+    }
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+    for (int j = 0; j < n; ++j) {
+        const float4 v = p[s[j]];
+        sx += v.x; sy += v.y; sz += v.z; si += v.w;
+    }
+    const float cnt = (float)n;
+    out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
 }
 
 __global__ void k_xyzi4_to_aos(const float4* __restrict__ src, int n, unsigned char* __restrict__ dst, size_t stride)
@@ -267,10 +352,18 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, Buf& out, int* n_ou
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(list.alloc(sizeof(int) * (size_t)(no ? no : 1)));
     HIPCHK(out.alloc(sizeof(float4) * (size_t)(no ? no : 1)));
+    Buf large;                                               // [0] = count, [1..] = output slots of crowded voxels
+    HIPCHK(large.alloc(sizeof(int) * ((size_t)no + 1)));
+    HIPCHK(hipMemsetAsync(large.p, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_vox_list, dim3(nk), dim3(256), 0, s, start.as<int>(), rank.as<int>(), g.n_keys, list.as<int>());
-    if (no)
-        hipLaunchKernelGGL(k_vox_centroid, dim3((no + 3) / 4), dim3(256), 0, s, d_in, start.as<int>(), list.as<int>(), no,
+    if (no) {
+        hipLaunchKernelGGL(k_vox_centroid_small, dim3((no + 255) / 256), dim3(256), 0, s, d_in, start.as<int>(), list.as<int>(), no,
                            tmp.as<int>(), out.as<float4>());
+        hipLaunchKernelGGL(k_vox_centroid, dim3((no + 3) / 4), dim3(256), 0, s, d_in, start.as<int>(), list.as<int>(), no,
+                           tmp.as<int>(), out.as<float4>(), large.as<int>() + 1, large.as<int>());
+        hipLaunchKernelGGL(k_vox_centroid_large, dim3(no < 1024 ? no : 1024), dim3(256), 0, s, d_in, start.as<int>(), list.as<int>(),
+                           tmp.as<int>(), out.as<float4>(), large.as<int>() + 1, large.as<int>());
+    }
     HIPCHK(hipStreamSynchronize(s));       // temporaries are freed on return
     HIPCHK(hipGetLastError());
     *n_out = no;

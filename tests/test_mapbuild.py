@@ -81,6 +81,18 @@ def test_gpu_voxel_grid_edge_cases(pkg, oracle):
     out_o, _ = oracle.voxel_grid(dense, 0.5)
     np.testing.assert_array_equal(out_g.view(np.uint32), out_o.view(np.uint32))
     assert len(out_g) <= 8
+    # every tier of the centroid pass in one cloud: voxels with 1..32 points (one thread each), 33..128 (one
+    # wave), 129..4096 (one workgroup, bitonic sort) and > 4096 (exact fallback)
+    tiers = [_cloud(rng, 40000, extent=(20, 20, 2))]
+    for k, cnt in enumerate((60, 128, 129, 700, 4096, 4097, 9000)):
+        blob = _cloud(rng, cnt, extent=(0.3, 0.3, 0.3))
+        blob[:, :3] = blob[:, :3] * 0.3 + np.array([40.2 + 2.0 * k, 0.2, 0.2], np.float32)   # inside one 0.5 m voxel
+        tiers.append(blob)
+    mixed = np.concatenate(tiers)
+    mixed = mixed[rng.permutation(len(mixed))]
+    out_g, _ = pkg.voxel_grid(mixed, 0.5)
+    out_o, _ = oracle.voxel_grid(mixed, 0.5)
+    np.testing.assert_array_equal(out_g.view(np.uint32), out_o.view(np.uint32))
     # overflow: pass-through, status 1
     big = _cloud(rng, 500, extent=(100, 100, 100))
     out_g, rc = pkg.voxel_grid(big, 0.01)
