@@ -794,6 +794,12 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
 #pragma unroll
         for (int pp = 0; pp < PPT; ++pp) any = any || act[pp];
         if (!__syncthreads_or(any ? 1 : 0)) {
+            // the search bound of a point is only valid from one pass to the very next: drop it for points that sit this pass out
+            if (P.d5_cache) {
+#pragma unroll
+                for (int pp = 0; pp < PPT; ++pp)
+                    if (inr[pp]) P.d5_cache[base + bd.first + pp * LIO_BLOCK + (int)threadIdx.x] = -1.0f;
+            }
             if (wave != 0) return;
             double* part0 = P.partials + ((size_t)bd.scan * P.max_blk + bd.blk) * LIO_SUMS;
             if (lane < 28) __hip_atomic_store(part0 + lane, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
