@@ -707,7 +707,7 @@ LIO_DEV void lio_arrive_and_finish(const LioIterParams& P, const LioBlockDesc& b
 template <int PPT, bool STAGE, bool CORNER>
 __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIterParams P)
 {
-    __shared__ __attribute__((aligned(16))) float s_rows[LIO_BLOCK][8];   // [arz ary arx cx cy cz | -cw | accepted]
+    __shared__ __attribute__((aligned(16))) double s_rows[LIO_BLOCK][8];  // [arz ary arx cx cy cz | -cw | accepted], widened once
     __shared__ double s_part[8][28];
     __shared__ double s_sum[28];
     __shared__ LioSolveWs s_ws;
@@ -979,14 +979,19 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
         float row[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, rhs = 0.0f;
         if (accept) lio_jacobian_row(tr, px[pp], py[pp], pz[pp], cxx, cyy, czz, cww, P.c.jac_exact, row, rhs);
         if (PPT > 1) __syncthreads();                                  // previous pass finished reading
-        reinterpret_cast<float4*>(s_rows[threadIdx.x])[0] = make_float4(row[0], row[1], row[2], row[3]);
-        reinterpret_cast<float4*>(s_rows[threadIdx.x])[1] = make_float4(row[4], row[5], rhs, accept ? 1.0f : 0.0f);
+        {   // each value is converted to fp64 once here instead of once per product below
+            double2* dst = reinterpret_cast<double2*>(s_rows[threadIdx.x]);
+            dst[0] = make_double2((double)row[0], (double)row[1]);
+            dst[1] = make_double2((double)row[2], (double)row[3]);
+            dst[2] = make_double2((double)row[4], (double)row[5]);
+            dst[3] = make_double2((double)rhs, accept ? 1.0 : 0.0);
+        }
         if (pp == 0) LIO_STAMP(3);
         __syncthreads();
         if (red_s < 28) {
 #pragma unroll 8
             for (int p = red_g; p < LIO_BLOCK; p += 8)
-                red_acc += (double)s_rows[p][red_a] * (double)s_rows[p][red_b];
+                red_acc = __builtin_fma(s_rows[p][red_a], s_rows[p][red_b], red_acc);   // the product of two widened fp32 is exact: fma == mul, add
         }
     }
     LIO_STAMP(4);
