@@ -121,6 +121,13 @@ def main():
     ap.add_argument("--lawnmower", action="store_true", help="keyframes on a lawn-mower path inside a 50 m radius (configs[3])")
     args = ap.parse_args()
 
+    # Exactly one line goes to stdout: native libraries print there too (RCCL writes a version banner at
+    # communicator creation), so file descriptor 1 is pointed at stderr for the whole run and the JSON line
+    # is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -215,7 +222,12 @@ def main():
     kcfg = dict(device_id=local_rank, profile=1, use_graph=1 if args.graph else 0, graph_iters=max(args.graph, 1), lookahead=args.lookahead, kernel_variant=args.variant,
                 use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch, nn_cache=args.nncache)
     if sharded:
-        runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2, **kcfg)
+        # the host runs `lookahead` GN iterations ahead of the convergence check (never 0 here: polling the
+        # iteration just enqueued would drain the GPU once per iteration and sub-batch)
+        kcfg_sh = dict(kcfg)
+        kcfg_sh.pop("lookahead")
+        runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2,
+                                     lookahead=max(args.lookahead, 2), **kcfg_sh)
         runner.upload(scans)
         s2m = runner.handles[0]
     else:
@@ -375,7 +387,7 @@ def main():
                 lat.scan2MapOptimization(scans[i], poses0[i])
             out["single_scan_ms_incl_h2d"] = 1e3 * (time.perf_counter() - t0) / n_lat
             lat.close()
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if runner:
         runner.close()
     else:

@@ -102,7 +102,7 @@ class ShardedRunner:
     """
 
     def __init__(self, pkg, map_xyz, rank, world, dist, torch, mode="map", groups=2, deterministic=False,
-                 lookahead=1, **cfg):
+                 lookahead=2, **cfg):
         self.rank, self.world, self.dist, self.torch = rank, world, dist, torch
         self.mode, self.deterministic, self.lookahead = mode, deterministic, lookahead
         self.handles = []
@@ -112,8 +112,11 @@ class ShardedRunner:
             self.idx = shard_points(map_xyz, self.plan, rank)
         else:
             self.idx = np.arange(len(map_xyz))
-        stream = torch.cuda.current_stream().cuda_stream
-        for _ in range(max(1, groups)):
+        # one stream per sub-batch: the latency-bound pieces of one sub-batch (all-reduce, solve) run under the
+        # association kernel of the other one
+        self.streams = [torch.cuda.Stream() for _ in range(max(1, groups))]
+        for k in range(max(1, groups)):
+            stream = self.streams[k].cuda_stream
             s2m = pkg.ScanToMap(**cfg)
             if mode == "map":
                 s2m.set_map(np.ascontiguousarray(map_xyz[self.idx]))
@@ -122,7 +125,7 @@ class ShardedRunner:
             else:
                 s2m.set_map(map_xyz)
                 s2m.set_scan_shard(rank, world)
-            s2m.set_stream(stream)           # kernels and collectives are ordered through torch's current stream
+            s2m.set_stream(stream)           # kernels and collectives of a sub-batch are ordered through its stream
             self.handles.append(s2m)
         self.split = []                      # (first, last) scan of every group
         self.sums, self.gathered = [], []
@@ -134,11 +137,13 @@ class ShardedRunner:
         bounds = [n * k // g for k in range(g + 1)]
         self.split = [(bounds[k], bounds[k + 1]) for k in range(g)]
         self.sums, self.gathered = [], []
-        for (a, b), h in zip(self.split, self.handles):
+        for k, ((a, b), h) in enumerate(zip(self.split, self.handles)):
             h.batch_upload(scans[a:b])
-            self.sums.append(self.torch.zeros((b - a, SUMS), dtype=self.torch.float64, device="cuda"))
-            self.gathered.append(self.torch.zeros((self.world * (b - a), SUMS), dtype=self.torch.float64, device="cuda")
-                                 if self.deterministic else None)
+            with self.torch.cuda.stream(self.streams[k]):
+                self.sums.append(self.torch.zeros((b - a, SUMS), dtype=self.torch.float64, device="cuda"))
+                self.gathered.append(self.torch.zeros((self.world * (b - a), SUMS), dtype=self.torch.float64, device="cuda")
+                                     if self.deterministic else None)
+        self.torch.cuda.synchronize()
 
     def set_poses(self, poses):
         poses = np.ascontiguousarray(poses, np.float32)
@@ -146,6 +151,10 @@ class ShardedRunner:
             h.batch_set_poses(poses[a:b])
 
     def _reduce(self, k):
+        with self.torch.cuda.stream(self.streams[k]):
+            return self._reduce_on_current_stream(k)
+
+    def _reduce_on_current_stream(self, k):
         dist = self.dist
         if self.deterministic:
             # bitwise reproducible across runs: gather, then sum in rank order
@@ -172,7 +181,8 @@ class ShardedRunner:
                 if not live[k]:
                     continue
                 if work[k] is not None:
-                    work[k].wait()                                   # the stream waits, the host does not
+                    with self.torch.cuda.stream(self.streams[k]):
+                        work[k].wait()                               # the sub-batch's stream waits, the host does not
                 h.batch_iter_apply(self.sums[k].data_ptr())          # MO:1784-1835 from the global sums
                 # MO:1857-1858 for every scan of the group.  Every rank solves the same sums, so every
                 # rank sees the same counts and stops issuing collectives at the same iteration.
