@@ -336,7 +336,7 @@ def main():
     if rank == 0:
         rt, rr = rmse_pair(poses, poses_true, synth)
         out["pose_rmse_vs_truth"] = {"trans_m": rt, "rot_rad": rr}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only (the other ranks would idle)
             cb, cpu_poses, cpu_iters = cpu_baseline(scans, map_xyz, poses0, args.cpu_seconds, log)
             out["cpu_baseline"] = cb
             k = len(cpu_poses)
