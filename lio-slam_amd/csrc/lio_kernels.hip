@@ -1013,6 +1013,17 @@ __global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIte
 #undef LIO_STAMP
 }
 
+// Compact per-scan summary for callers that only want the poses: [pose x6 | iter | status | converged | is_degenerate]
+__global__ void k_s2m_pack_summary(const LioScanState* __restrict__ st, int n_scans, float* __restrict__ out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_scans) return;
+    float* o = out + (size_t)s * 10;
+    for (int k = 0; k < 6; ++k) o[k] = st[s].pose[k];
+    o[6] = __int_as_float(st[s].iter); o[7] = __int_as_float(st[s].status);
+    o[8] = __int_as_float(st[s].converged); o[9] = __int_as_float(st[s].is_degenerate);
+}
+
 // Sharded mode: solve every scan from all-reduced sums (one wave per scan).
 __global__ void k_s2m_apply(LioScanState* __restrict__ st, int n_scans, const double* __restrict__ sums, LioConsts c,
                             int* __restrict__ n_active)
@@ -1103,6 +1114,11 @@ void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stag
         default: hipLaunchKernelGGL((k_s2m_iterate<4, false, false>), gr, bl, 0, s, P); break;
         }
     }
+}
+
+void lio_launch_pack_summary(const LioScanState* st, int n_scans, float* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_s2m_pack_summary, dim3((n_scans + 255) / 256), dim3(256), 0, s, st, n_scans, out);
 }
 
 void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,

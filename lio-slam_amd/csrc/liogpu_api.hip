@@ -79,6 +79,9 @@ struct lio_s2m_handle {
     std::vector<int> v_order, v_first, v_first_orig;
     bool defer_sync = false;                         // lio_s2m_register: one sync at the end of the call
     float* d_poses = nullptr; size_t cap_poses = 0;
+    float* d_summary = nullptr; size_t cap_summary = 0;   // [n_scans][10] compact results (lio_s2m_batch_results without `results`)
+    float* h_summary = nullptr; size_t cap_h_summary = 0; // pinned
+    bool host_state_stale = false;    // h_state misses device-side updates (matP ...) since a summary-only read
     LioBlockDesc* d_blocks = nullptr; size_t cap_blocks = 0;
     int n_blocks = 0, ppt = 1, max_blk = 1;
     double* d_partials = nullptr; size_t cap_partials = 0;
@@ -229,13 +232,14 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_state, h->d_poses, h->d_blocks, h->d_partials, h->d_arrive, h->d_rec_flag,
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
                      h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
-                     h->d_nn_cache };
+                     h->d_nn_cache, h->d_summary };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->ev_ok) {
         for (int i = 0; i < LIO_MAX_ITERS; ++i) {
             (void)hipEventDestroy(h->ev_beg[i]); (void)hipEventDestroy(h->ev_end[i]); (void)hipEventDestroy(h->ev_chk[i]);
         }
         if (h->h_active) (void)hipHostFree(h->h_active);
+        if (h->h_summary) (void)hipHostFree(h->h_summary);
         (void)hipEventDestroy(h->ev_map[0]);
         (void)hipEventDestroy(h->ev_map[1]);
     }
@@ -428,6 +432,14 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         if (n_pts[s] > max_n) max_n = n_pts[s];
     }
     if (total > 0x7fffffffull - 1024) return lio_fail(LIO_ERR_CAPACITY, "batch too large");
+    if (h->host_state_stale && h->n_scans > 0 && h->d_state) {
+        // the persistent members (matP / isDegenerate, MO:176-177) live in the device copy: bring the host copy
+        // up to date before it is edited and uploaded again
+        HIPCHK(hipMemcpyAsync(h->h_state.data(), h->d_state, (size_t)h->n_scans * sizeof(LioScanState),
+                              hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->host_state_stale = false;
     const size_t tt = total ? total : 1;
     HIPCHK(lio_grow(&h->d_sx, &h->cap_sxyz[0], tt));
     HIPCHK(lio_grow(&h->d_sy, &h->cap_sxyz[1], tt));
@@ -925,9 +937,33 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
     if (!h->ran) return lio_fail(LIO_ERR_ARG, "nothing has been run");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
-    HIPCHK(hipMemcpyAsync(h->h_state.data(), h->d_state, (size_t)h->n_scans * sizeof(LioScanState),
-                          hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (results) {
+        HIPCHK(hipMemcpyAsync(h->h_state.data(), h->d_state, (size_t)h->n_scans * sizeof(LioScanState),
+                              hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->host_state_stale = false;
+    } else {
+        // poses only: 40 bytes per scan through a pinned buffer instead of the whole state (1.5 KB per scan)
+        const size_t need = (size_t)h->n_scans * 10;
+        HIPCHK(lio_grow(&h->d_summary, &h->cap_summary, need));
+        if (h->cap_h_summary < need) {
+            if (h->h_summary) HIPCHK(hipHostFree(h->h_summary));
+            h->h_summary = nullptr; h->cap_h_summary = 0;
+            HIPCHK(hipHostMalloc((void**)&h->h_summary, (need + 64) * sizeof(float), hipHostMallocDefault));
+            h->cap_h_summary = need + 64;
+        }
+        h->host_state_stale = true;
+        lio_launch_pack_summary(h->d_state, h->n_scans, h->d_summary, h->stream);
+        HIPCHK(hipMemcpyAsync(h->h_summary, h->d_summary, need * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int s = 0; s < h->n_scans; ++s) {
+            LioScanState& st = h->h_state[s];
+            const float* o = h->h_summary + (size_t)s * 10;
+            memcpy(st.pose, o, sizeof(float) * 6);
+            memcpy(&st.iter, o + 6, 4); memcpy(&st.status, o + 7, 4);
+            memcpy(&st.converged, o + 8, 4); memcpy(&st.is_degenerate, o + 9, 4);
+        }
+    }
     HIPCHK(hipGetLastError());
     int64_t pit = 0;
     for (int s = 0; s < h->n_scans; ++s) {

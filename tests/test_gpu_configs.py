@@ -111,3 +111,27 @@ def test_neighbour_cache_is_exact(pkg, oracle, small_case):
     po, ro, _, corr = oracle.scan2map(cfg, q["scan"], small_case["map"], q["pose_init"], corr_iter=3)
     assert np.array_equal(b[3][0], corr[0]) and np.array_equal(b[3][2], corr[2])
     assert list(ro.n_corr_iter)[:8] == b[2][:8]
+
+
+def test_persistent_members_survive_pose_only_reads(pkg, synth):
+    """isDegenerate / matP are members of the node (MO:176-177): a registration that never reaches the solve
+    (< 50 correspondences, MO:1721-1724) leaves them as the previous frame set them -- also when the
+    previous results were read back poses-only (the compact summary path)."""
+    import numpy as np
+    case = synth.make_case("vlp16", n_keyframes=4, seed=22, kind="corridor", device="cpu")
+    q = case["queries"][0]
+    s2m = pkg.ScanToMap()
+    s2m.set_map(case["map"])
+    s2m.batch_upload([q["scan"]]); s2m.batch_set_poses(q["pose_init"][None]); s2m.batch_run()
+    poses, _ = s2m.batch_results(with_results=False)                 # poses only
+    ref = pkg.ScanToMap()
+    ref.set_map(case["map"])
+    _, res_ref, _ = ref.scan2MapOptimization(q["scan"], q["pose_init"])
+    assert res_ref.is_degenerate == 1
+    tiny = q["scan"][:40]                                            # > 30 points, < 50 correspondences
+    s2m.batch_upload([tiny]); s2m.batch_set_poses(poses); s2m.batch_run()
+    _, res = s2m.batch_results(with_results=True)
+    assert res[0].status == 2                                        # LIO_TOO_FEW_CORR: pose untouched, members untouched
+    assert res[0].is_degenerate == 1
+    assert np.array_equal(np.array(res[0].matP, np.float32), np.array(res_ref.matP, np.float32))
+    s2m.close(); ref.close()
