@@ -246,6 +246,33 @@ int  lio_deskew(const lio_deskew_config *cfg, const void *pts, size_t n, size_t 
                 const double *imuRotZ, int32_t imuPointerCur,
                 void *out, size_t out_stride_bytes, size_t *n_out);
 
+/* ---- EXTENSION beyond this reference: the range-image build -------------------------------
+ * BASELINE.json's north_star names "imageProjection's deskew/range-image build"; this fork's
+ * projectPointCloud IP:577-615 no longer builds one and nothing in the fork fills
+ * startRingIndex / endRingIndex / pointColInd / pointRange (MSG:4-8), which its own
+ * featureExtraction.cpp reads.  lio_range_image is projectPointCloud +
+ * cloudExtraction of upstream LIO-SAM (Velodyne/Ouster column rule, first point per range-image
+ * cell wins) with this fork's deskewPoint IP:545-575, i.e. the producer lio_extract_features
+ * needs.  No reference oracle exists for it (parity unpinned; checked against
+ * oracle/lio_oracle.c lo_range_image only).
+ * pts: PointXYZIRT records as for lio_deskew.  out: PointXYZI-compatible records, room for
+ * N_SCAN * Horizon_SCAN; pointColInd / pointRange the same; startRingIndex / endRingIndex:
+ * N_SCAN entries.  *n_out = points kept (ring-major, ascending column). */
+typedef struct lio_range_image_config {
+    int32_t N_SCAN, Horizon_SCAN, downsampleRate;
+    float   lidarMinRange, lidarMaxRange;
+    int32_t deskew_flag;     /* -1 = no per-point time field */
+    int32_t device_id;
+} lio_range_image_config;
+void lio_range_image_default_config(lio_range_image_config *cfg);
+int  lio_range_image(const lio_range_image_config *cfg, const void *pts, size_t n, size_t stride_bytes,
+                     double time_scan_cur,
+                     const double *imuTime, const double *imuRotX, const double *imuRotY,
+                     const double *imuRotZ, int32_t imuPointerCur,
+                     void *out, size_t out_stride_bytes, size_t *n_out,
+                     int32_t *startRingIndex, int32_t *endRingIndex,
+                     int32_t *pointColInd, float *pointRange);
+
 /* calculateSmoothness, FE:81-101: curvature[i] for i in [5, n-5), also zeroes
  * neighbor_picked / label there (either may be NULL).  Host pointers. */
 int  lio_curvature(int32_t device_id, const float *range, size_t n, float *curvature,

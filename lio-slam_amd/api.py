@@ -66,6 +66,12 @@ class DeskewConfig(C.Structure):
     ]
 
 
+class RangeImageConfig(C.Structure):
+    _fields_ = [("N_SCAN", C.c_int32), ("Horizon_SCAN", C.c_int32), ("downsampleRate", C.c_int32),
+                ("lidarMinRange", C.c_float), ("lidarMaxRange", C.c_float), ("deskew_flag", C.c_int32),
+                ("device_id", C.c_int32)]
+
+
 class FeatureConfig(C.Structure):
     _fields_ = [("N_SCAN", C.c_int32), ("edgeThreshold", C.c_float), ("surfThreshold", C.c_float),
                 ("surfLeafSize", C.c_float), ("device_id", C.c_int32)]
@@ -101,6 +107,7 @@ EXPORTS = [
     "lio_kf_store_count", "lio_assemble_map_resident", "lio_s2m_set_scan_shard",
     "lio_s2m_set_corner_map", "lio_s2m_batch_upload_corners", "lio_s2m_register_cs",
     "lio_s2m_get_corner_correspondences", "lio_feature_default_config", "lio_extract_features",
+    "lio_range_image_default_config", "lio_range_image",
 ]
 
 
@@ -154,6 +161,10 @@ def load_library():
     L.lio_deskew.argtypes = [C.POINTER(DeskewConfig), vp, sz, sz, f64, dp, dp, dp, dp, i32, vp, sz,
                              C.POINTER(sz)]
     L.lio_curvature.argtypes = [i32, vp, sz, vp, vp, vp]
+    L.lio_range_image_default_config.argtypes = [C.POINTER(RangeImageConfig)]
+    L.lio_range_image_default_config.restype = None
+    L.lio_range_image.argtypes = [C.POINTER(RangeImageConfig), vp, sz, sz, f64, dp, dp, dp, dp, i32, vp, sz, C.POINTER(sz),
+                                  vp, vp, vp, vp]
     L.lio_feature_default_config.argtypes = [C.POINTER(FeatureConfig)]
     L.lio_feature_default_config.restype = None
     L.lio_extract_features.argtypes = [C.POINTER(FeatureConfig), vp, sz, sz, vp, vp, vp, vp, vp, C.POINTER(sz), vp,
@@ -439,6 +450,34 @@ def curvature(rng, device_id=0):
     _check(load_library().lio_curvature(device_id, r.ctypes.data, len(r), curv.ctypes.data,
                                         picked.ctypes.data, label.ctypes.data), "lio_curvature")
     return curv, picked, label
+
+
+# extension (row A4): projectPointCloud + cloudExtraction of upstream LIO-SAM -> the cloud_info arrays FE consumes
+def range_image(records, t_cur, imu, device_id=0, **cfg_overrides):
+    """PointXYZIRT records -> dict(cloud [n,4], start_ring, end_ring, col, range) like synth.organize_scan."""
+    L = load_library()
+    cfg = RangeImageConfig()
+    L.lio_range_image_default_config(C.byref(cfg))
+    cfg.device_id = device_id
+    for k, v in cfg_overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    cur, T, RX, RY, RZ = imu
+    rec = np.ascontiguousarray(records)
+    cells = int(cfg.N_SCAN) * int(cfg.Horizon_SCAN)
+    out = _scratch("ri_cloud", (max(cells, 1), 8))
+    col = _scratch("ri_col", (max(cells, 1),), np.int32)
+    rng = _scratch("ri_range", (max(cells, 1),))
+    start = np.zeros(cfg.N_SCAN, np.int32)
+    end = np.zeros(cfg.N_SCAN, np.int32)
+    n_out = C.c_size_t()
+    dpp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    _check(L.lio_range_image(C.byref(cfg), rec.ctypes.data, len(rec), rec.dtype.itemsize, t_cur, dpp(T), dpp(RX), dpp(RY), dpp(RZ),
+                             cur, out.ctypes.data, 32, C.byref(n_out), start.ctypes.data, end.ctypes.data, col.ctypes.data,
+                             rng.ctypes.data), "lio_range_image")
+    n = n_out.value
+    return {"cloud": _from_records(out, n), "start_ring": start, "end_ring": end, "col": col[:n].copy(), "range": rng[:n].copy()}
 
 
 # markOccludedPoints + extractFeatures, FE:103-238 (with calculateSmoothness: the whole handler FE:67-77)

@@ -216,6 +216,128 @@ __global__ __launch_bounds__(256) void k_deskew_emit(LioDeskewParams P, const un
     o[4] = pi;                                       // IP:572
 }
 
+// ------------------------------------------------------------------ range image (extension, row A4)
+// projectPointCloud + cloudExtraction of upstream LIO-SAM on top of this fork's deskewPoint: see
+// oracle/lio_oracle.c lo_range_image for the semantics and why this is an extension.
+struct LioRangeImageParams {
+    LioDeskewParams d;          // pts, stride, n, N_SCAN, downsampleRate, maxRange, IMU tables, do_deskew
+    int H;                      // Horizon_SCAN
+    float minRange;
+};
+
+// row / column of a raw point, or -1 when upstream's projectPointCloud drops it
+LIO_DEV int lio_ri_cell(const LioRangeImageParams& P, float x, float y, float z, int ring, float& range)
+{
+    range = sqrtf(x * x + y * y + z * z);
+    if (range < P.minRange || range > P.d.maxRange) return -1;
+    if (ring < 0 || ring >= P.d.N_SCAN) return -1;
+    if (ring % P.d.downsampleRate != 0) return -1;
+    const float at = (float)atan2((double)x, (double)y);
+    const float at180 = at * 180;
+    const float horizonAngle = (float)((double)at180 / 3.14159265358979323846);
+    const float ang_res_x = (float)(360.0 / (double)(float)P.H);
+    int col = (int)(-round(((double)horizonAngle - 90.0) / (double)ang_res_x) + (double)(P.H / 2));
+    if (col >= P.H) col -= P.H;
+    if (col < 0 || col >= P.H) return -1;
+    return ring * P.H + col;
+}
+
+// pass 1: the first input point of every cell (atomicMin on the input index) and the first accepted point overall
+__global__ __launch_bounds__(256) void k_ri_first(LioRangeImageParams P, int* __restrict__ cell_first, int* __restrict__ first_idx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.d.n) return;
+    const unsigned char* rec = P.d.pts + (size_t)i * P.d.stride;
+    const float* f = reinterpret_cast<const float*>(rec);
+    float range;
+    const int cell = lio_ri_cell(P, f[0], f[1], f[2], *reinterpret_cast<const unsigned short*>(rec + 20), range);
+    if (cell < 0) return;
+    atomicMin(&cell_first[cell], i);
+    atomicMin(first_idx, i);
+}
+
+// pass 2: one thread per cell: deskew the winner, write it at its rank among the occupied cells (ring-major,
+// ascending column = ascending cell index), with its column and raw range
+__global__ __launch_bounds__(256) void k_ri_extract(LioRangeImageParams P, const int* __restrict__ cell_first,
+                                                    const int* __restrict__ cell_rank, const int* __restrict__ first_idx,
+                                                    unsigned char* __restrict__ out, size_t out_stride,
+                                                    int* __restrict__ col_out, float* __restrict__ range_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* s_inv = reinterpret_cast<float*>(smem);
+    double* sT = reinterpret_cast<double*>(smem + 64);
+    const int nt = P.d.imuPointerCur + 1;
+    double* sX = sT + nt; double* sY = sX + nt; double* sZ = sY + nt;
+    if (P.d.do_deskew) {
+        for (int k = threadIdx.x; k < nt; k += 256) {
+            sT[k] = P.d.imuTime[k]; sX[k] = P.d.imuRotX[k]; sY[k] = P.d.imuRotY[k]; sZ[k] = P.d.imuRotZ[k];
+        }
+    }
+    __syncthreads();
+    if (P.d.do_deskew && threadIdx.x == 0) {
+        const int fi = *first_idx;                           // firstPointFlag: the first point that reaches deskewPoint
+        float inv[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+        if (fi < P.d.n) {
+            const float tf = *reinterpret_cast<const float*>(P.d.pts + (size_t)fi * P.d.stride + 24);
+            float rx, ry, rz, L[9];
+            lio_find_rotation(P.d.time_scan_cur + (double)tf, sT, sX, sY, sZ, P.d.imuPointerCur, rx, ry, rz);
+            lio_rot_rpy(rx, ry, rz, L);
+            lio_inv3(L, inv);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_inv[k] = inv[k];
+    }
+    __syncthreads();
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= P.d.N_SCAN * P.H) return;
+    const int i = cell_first[cell];
+    if (i == 0x7fffffff) return;
+    const int pos = cell_rank[cell];
+    const unsigned char* rec = P.d.pts + (size_t)i * P.d.stride;
+    const float* f = reinterpret_cast<const float*>(rec);
+    const float px = f[0], py = f[1], pz = f[2], pi = f[4];
+    float ox = px, oy = py, oz = pz;
+    if (P.d.do_deskew) {
+        float rx, ry, rz, L[9], Bt[9];
+        lio_find_rotation(P.d.time_scan_cur + (double)f[6], sT, sX, sY, sZ, P.d.imuPointerCur, rx, ry, rz);
+        lio_rot_rpy(rx, ry, rz, L);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                Bt[r * 3 + c] = s_inv[r * 3 + 0] * L[0 * 3 + c] + s_inv[r * 3 + 1] * L[1 * 3 + c]
+                              + s_inv[r * 3 + 2] * L[2 * 3 + c];
+        ox = Bt[0] * px + Bt[1] * py + Bt[2] * pz + 0.0f;
+        oy = Bt[3] * px + Bt[4] * py + Bt[5] * pz + 0.0f;
+        oz = Bt[6] * px + Bt[7] * py + Bt[8] * pz + 0.0f;
+    }
+    float* o = reinterpret_cast<float*>(out + (size_t)pos * out_stride);
+    o[0] = ox; o[1] = oy; o[2] = oz; o[3] = 1.0f; o[4] = pi;
+    col_out[pos] = cell % P.H;
+    range_out[pos] = sqrtf(px * px + py * py + pz * pz);
+}
+
+__global__ void k_ri_fill(int* __restrict__ p, int n, int v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void k_ri_flags(const int* __restrict__ cell_first, int n_cells, int* __restrict__ flag)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_cells) flag[c] = cell_first[c] != 0x7fffffff ? 1 : 0;
+}
+
+// startRingIndex = (points before the ring) - 1 + 5, endRingIndex = (points up to and including the ring) - 1 - 5
+__global__ void k_ri_rings(const int* __restrict__ cell_rank, int n_scan, int H, int* __restrict__ start, int* __restrict__ end)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_scan) return;
+    start[i] = cell_rank[i * H] - 1 + 5;
+    end[i] = cell_rank[(i + 1) * H] - 1 - 5;
+}
+
 // K2: 11-tap range curvature, summation order exactly as FE:86-91
 __global__ __launch_bounds__(256) void k_curvature(const float* __restrict__ r, int n, float* __restrict__ curv,
                                                    int* __restrict__ picked, int* __restrict__ label)
@@ -351,5 +473,108 @@ extern "C" int lio_curvature(int32_t device_id, const float* range, size_t n, fl
     if (label) HIPCHK(hipMemcpyAsync(label, d_l.p, n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipGetLastError());
+    return LIO_OK;
+}
+
+void lio_launch_exclusive_scan(const int* in, int n, int* tile_sums, int* out, hipStream_t s);   // lio_kernels.hip
+int  lio_scan_tiles(int n_cells);
+
+extern "C" void lio_range_image_default_config(lio_range_image_config* c)
+{
+    memset(c, 0, sizeof(*c));
+    c->N_SCAN = 16;
+    c->Horizon_SCAN = 1800;
+    c->downsampleRate = 1;
+    c->lidarMinRange = 1.0f;       // upstream params.yaml
+    c->lidarMaxRange = 1000.0f;
+    c->deskew_flag = 1;
+    c->device_id = 0;
+}
+
+extern "C" int lio_range_image(const lio_range_image_config* cfg, const void* pts, size_t n, size_t stride,
+                               double time_scan_cur,
+                               const double* imuTime, const double* imuRotX, const double* imuRotY,
+                               const double* imuRotZ, int32_t imuPointerCur,
+                               void* out, size_t out_stride, size_t* n_out,
+                               int32_t* startRingIndex, int32_t* endRingIndex,
+                               int32_t* pointColInd, float* pointRange)
+{
+    if (!cfg || !n_out || !startRingIndex || !endRingIndex || (n && !pts))
+        return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
+    if (stride < 28 || (stride & 3) || out_stride < 20 || (out_stride & 3))
+        return lio_fail_ext(LIO_ERR_ARG, "PointXYZIRT stride must be >= 28, output stride >= 20, multiples of 4", hipSuccess);
+    if (cfg->N_SCAN < 1 || cfg->N_SCAN > 1024 || cfg->Horizon_SCAN < 1 || cfg->Horizon_SCAN > 32767 || cfg->downsampleRate < 1)
+        return lio_fail_ext(LIO_ERR_ARG, "N_SCAN in 1..1024, Horizon_SCAN in 1..32767, downsampleRate >= 1", hipSuccess);
+    if (n > 0x7fffffffull - 1024) return lio_fail_ext(LIO_ERR_CAPACITY, "cloud too large", hipSuccess);
+    const bool imu_available = imuPointerCur > 0;
+    const bool do_deskew = !(cfg->deskew_flag == -1 || !imu_available);
+    if (do_deskew && (!imuTime || !imuRotX || !imuRotY || !imuRotZ || imuPointerCur >= 2000))
+        return lio_fail_ext(LIO_ERR_ARG, "IMU tables missing or imuPointerCur >= 2000 (IP:62)", hipSuccess);
+    const int ns = cfg->N_SCAN, H = cfg->Horizon_SCAN, cells = ns * H;
+    *n_out = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return lio_fail_ext(LIO_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)", hipSuccess);
+    HIPCHK(hipSetDevice(cfg->device_id));
+    (void)hipGetLastError();
+
+    const int nt = do_deskew ? imuPointerCur + 1 : 0;
+    DevBuf d_pts, d_first, d_flag, d_rank, d_tiles, d_misc, d_imu, d_out, d_col, d_range, d_rings;
+    HIPCHK(d_pts.alloc((n ? n : 1) * stride));
+    HIPCHK(d_first.alloc(sizeof(int) * (size_t)cells));
+    HIPCHK(d_flag.alloc(sizeof(int) * (size_t)cells));
+    HIPCHK(d_rank.alloc(sizeof(int) * ((size_t)cells + 1)));
+    HIPCHK(d_tiles.alloc(sizeof(int) * ((size_t)lio_scan_tiles(cells) + 1)));
+    HIPCHK(d_misc.alloc(sizeof(int)));
+    HIPCHK(d_imu.alloc(sizeof(double) * 4 * (size_t)(nt ? nt : 1)));
+    HIPCHK(d_out.alloc((size_t)cells * out_stride));
+    HIPCHK(d_col.alloc(sizeof(int) * (size_t)cells));
+    HIPCHK(d_range.alloc(sizeof(float) * (size_t)cells));
+    HIPCHK(d_rings.alloc(sizeof(int) * 2 * (size_t)ns));
+    hipStream_t s = nullptr;
+    if (n) HIPCHK(hipMemcpyAsync(d_pts.p, pts, n * stride, hipMemcpyHostToDevice, s));
+    double* di = d_imu.as<double>();
+    if (nt) {
+        HIPCHK(hipMemcpyAsync(di, imuTime, sizeof(double) * nt, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(di + nt, imuRotX, sizeof(double) * nt, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(di + 2 * nt, imuRotY, sizeof(double) * nt, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(di + 3 * nt, imuRotZ, sizeof(double) * nt, hipMemcpyHostToDevice, s));
+    }
+    const int big = 0x7fffffff;
+    HIPCHK(hipMemcpyAsync(d_misc.p, &big, sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_out.p, 0, (size_t)cells * out_stride, s));
+
+    LioRangeImageParams P;
+    P.d.pts = d_pts.as<unsigned char>(); P.d.stride = stride; P.d.n = (int)n;
+    P.d.N_SCAN = ns; P.d.downsampleRate = cfg->downsampleRate; P.d.point_filter_num = 1;
+    P.d.minFront = P.d.minBack = P.d.minLeft = P.d.minRight = 0.0f;
+    P.d.maxRange = cfg->lidarMaxRange; P.d.maxIntensity = 0.0f;
+    P.d.do_deskew = do_deskew ? 1 : 0; P.d.time_scan_cur = time_scan_cur;
+    P.d.imuTime = di; P.d.imuRotX = di + nt; P.d.imuRotY = di + 2 * nt; P.d.imuRotZ = di + 3 * nt;
+    P.d.imuPointerCur = do_deskew ? imuPointerCur : 0;
+    P.H = H; P.minRange = cfg->lidarMinRange;
+
+    const int nb = (int)((n + 255) / 256), nc = (cells + 255) / 256;
+    hipLaunchKernelGGL(k_ri_fill, dim3(nc), dim3(256), 0, s, d_first.as<int>(), cells, 0x7fffffff);   // rangeMat = FLT_MAX
+    if (n) hipLaunchKernelGGL(k_ri_first, dim3(nb), dim3(256), 0, s, P, d_first.as<int>(), d_misc.as<int>());
+    hipLaunchKernelGGL(k_ri_flags, dim3(nc), dim3(256), 0, s, d_first.as<int>(), cells, d_flag.as<int>());
+    lio_launch_exclusive_scan(d_flag.as<int>(), cells, d_tiles.as<int>(), d_rank.as<int>(), s);
+    const size_t lds = 64 + sizeof(double) * 4 * (size_t)(nt ? nt : 1);
+    hipLaunchKernelGGL(k_ri_extract, dim3(nc), dim3(256), lds, s, P, d_first.as<int>(), d_rank.as<int>(), d_misc.as<int>(),
+                       d_out.as<unsigned char>(), out_stride, d_col.as<int>(), d_range.as<float>());
+    hipLaunchKernelGGL(k_ri_rings, dim3((ns + 255) / 256), dim3(256), 0, s, d_rank.as<int>(), ns, H,
+                       d_rings.as<int>(), d_rings.as<int>() + ns);
+    int total = 0;
+    HIPCHK(hipMemcpyAsync(&total, d_rank.as<int>() + cells, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(startRingIndex, d_rings.p, sizeof(int) * (size_t)ns, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(endRingIndex, d_rings.as<int>() + ns, sizeof(int) * (size_t)ns, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    *n_out = (size_t)total;
+    if (total > 0) {
+        if (out) HIPCHK(hipMemcpy(out, d_out.p, (size_t)total * out_stride, hipMemcpyDeviceToHost));
+        if (pointColInd) HIPCHK(hipMemcpy(pointColInd, d_col.p, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost));
+        if (pointRange) HIPCHK(hipMemcpy(pointRange, d_range.p, sizeof(float) * (size_t)total, hipMemcpyDeviceToHost));
+    }
     return LIO_OK;
 }

@@ -1149,6 +1149,98 @@ int lo_voxel_grid(const float *in_xyzi, size_t n, float leaf, float *out_xyzi, s
 }
 
 /* =========================================================================
+ * EXTENSION BEYOND THE REFERENCE -- the range-image build.
+ *
+ * BASELINE.json's north_star names "imageProjection's deskew/range-image build".  This fork's
+ * projectPointCloud IP:577-615 no longer builds a range image (it filters and deskews in input
+ * order), and nothing in it fills startRingIndex / endRingIndex / pointColInd / pointRange
+ * (MSG:4-8), which its featureExtraction.cpp still reads.  What follows restates projectPointCloud
+ * + cloudExtraction of upstream LIO-SAM (TixiaoShan/LIO-SAM imageProjection.cpp, Velodyne/Ouster
+ * column rule; not present under /root/reference) on top of THIS fork's deskewPoint IP:545-575.
+ * There is no reference oracle for it in this tree: parity unpinned, self-consistency tests only.
+ *
+ *   per input point, in order: range = |p|, drop if outside [lidarMinRange, lidarMaxRange]; row = ring,
+ *   drop if outside [0, N_SCAN) or row % downsampleRate != 0; column from the azimuth,
+ *   horizonAngle = atan2(x, y) * 180 / pi, col = -round((horizonAngle - 90) / (360 / H)) + H / 2,
+ *   wrapped once, dropped if outside [0, H); a cell keeps the FIRST point that lands in it; that
+ *   point is deskewed (the reference transform comes from the first point that gets this far).
+ *   cloudExtraction: ring-major, ascending column; startRingIndex = first - 1 + 5, endRingIndex =
+ *   last - 5; pointColInd / pointRange per kept point (range of the RAW point).
+ * atan2 is defined as the fp64 function rounded once to fp32, like the trig of the pose.
+ * ========================================================================= */
+size_t lo_range_image(const lo_deskew_config *cfg, int horizon_scan, float lidar_min_range,
+                      const float *x, const float *y, const float *z,
+                      const float *intensity, const uint16_t *ring, const float *time,
+                      size_t n, double time_scan_cur,
+                      const double *imuTime, const double *imuRotX,
+                      const double *imuRotY, const double *imuRotZ, int imuPointerCur,
+                      float *out_xyzi, int32_t *startRingIndex, int32_t *endRingIndex,
+                      int32_t *pointColInd, float *pointRange)
+{
+    const int H = horizon_scan, NS = cfg->N_SCAN;
+    const size_t cells = (size_t)H * (size_t)NS;
+    float *rangeMat = (float *)malloc(sizeof(float) * (cells ? cells : 1));
+    float *full = (float *)malloc(sizeof(float) * 4 * (cells ? cells : 1));
+    for (size_t c = 0; c < cells; ++c) rangeMat[c] = FLT_MAX;
+    int first_point = 1;
+    float startInv[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    const float ang_res_x = (float)(360.0 / (double)(float)H);
+    for (size_t i = 0; i < n; ++i) {
+        float px = x[i], py = y[i], pz = z[i], pi = intensity[i];
+        float range = sqrtf(px * px + py * py + pz * pz);
+        if (range < lidar_min_range || range > cfg->lidarMaxRange) continue;
+        int rowIdn = ring[i];
+        if (rowIdn < 0 || rowIdn >= NS) continue;
+        if (rowIdn % cfg->downsampleRate != 0) continue;
+        float at = (float)atan2((double)px, (double)py);               /* atan2(float, float) */
+        float at180 = at * 180;                                         /* float * int */
+        float horizonAngle = (float)((double)at180 / M_PI);             /* ... / M_PI in double, stored as float */
+        int columnIdn = (int)(-round(((double)horizonAngle - 90.0) / (double)ang_res_x) + (double)(H / 2));
+        if (columnIdn >= H) columnIdn -= H;
+        if (columnIdn < 0 || columnIdn >= H) continue;
+        const size_t index = (size_t)columnIdn + (size_t)rowIdn * (size_t)H;
+        if (rangeMat[index] != FLT_MAX) continue;
+
+        float ox = px, oy = py, oz = pz;
+        if (!(cfg->deskew_flag == -1 || !cfg->imu_available)) {         /* deskewPoint, IP:545-575 */
+            double pointTime = time_scan_cur + (double)time[i];
+            float rx, ry, rz;
+            lo_find_rotation(pointTime, imuTime, imuRotX, imuRotY, imuRotZ, imuPointerCur, &rx, &ry, &rz);
+            float T[12];
+            lo_get_transformation(0, 0, 0, rx, ry, rz, T, cfg->trig_mode);
+            float L[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
+            if (first_point) { lo_inv3(L, startInv); first_point = 0; }
+            float Bt[9];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c)
+                    Bt[r * 3 + c] = startInv[r * 3 + 0] * L[0 * 3 + c] + startInv[r * 3 + 1] * L[1 * 3 + c]
+                                  + startInv[r * 3 + 2] * L[2 * 3 + c];
+            ox = Bt[0] * px + Bt[1] * py + Bt[2] * pz + 0.0f;
+            oy = Bt[3] * px + Bt[4] * py + Bt[5] * pz + 0.0f;
+            oz = Bt[6] * px + Bt[7] * py + Bt[8] * pz + 0.0f;
+        }
+        rangeMat[index] = range;
+        full[4 * index + 0] = ox; full[4 * index + 1] = oy; full[4 * index + 2] = oz; full[4 * index + 3] = pi;
+    }
+    size_t count = 0;                                                    /* cloudExtraction */
+    for (int i = 0; i < NS; ++i) {
+        startRingIndex[i] = (int32_t)count - 1 + 5;
+        for (int j = 0; j < H; ++j) {
+            const size_t index = (size_t)j + (size_t)i * (size_t)H;
+            if (rangeMat[index] != FLT_MAX) {
+                pointColInd[count] = j;
+                pointRange[count] = rangeMat[index];
+                memcpy(out_xyzi + 4 * count, full + 4 * index, sizeof(float) * 4);
+                ++count;
+            }
+        }
+        endRingIndex[i] = (int32_t)count - 1 - 5;
+    }
+    free(rangeMat); free(full);
+    return count;
+}
+
+/* =========================================================================
  * featureExtraction.cpp, the rest of laserCloudInfoHandler FE:67-79:
  * markOccludedPoints FE:103-139 and extractFeatures FE:141-238, consuming the cloud_info arrays
  * (startRingIndex, endRingIndex, pointColInd, pointRange; MSG:4-8) exactly as the reference does.

@@ -196,6 +196,17 @@ void lo_transform_point_cloud(const float *in_xyzi, size_t n, const float pose[6
 /* pcl::VoxelGrid centroid filter (MO:1605-1611, MO:1581-1583); out has room for n points */
 int  lo_voxel_grid(const float *in_xyzi, size_t n, float leaf, float *out_xyzi, size_t *n_out);
 
+/* ---- EXTENSION beyond the reference: range-image build + cloudExtraction of upstream LIO-SAM (row A4;
+ * parity unpinned).  out_xyzi / pointColInd / pointRange need room for N_SCAN * horizon_scan entries. */
+size_t lo_range_image(const lo_deskew_config *cfg, int horizon_scan, float lidar_min_range,
+                      const float *x, const float *y, const float *z,
+                      const float *intensity, const uint16_t *ring, const float *time,
+                      size_t n, double time_scan_cur,
+                      const double *imuTime, const double *imuRotX,
+                      const double *imuRotY, const double *imuRotZ, int imuPointerCur,
+                      float *out_xyzi, int32_t *startRingIndex, int32_t *endRingIndex,
+                      int32_t *pointColInd, float *pointRange);
+
 /* featureExtraction.cpp FE:103-238 */
 void lo_mark_occluded(const float *pointRange, const int32_t *pointColInd, size_t n, int32_t *picked);
 int lo_extract_features(const float *cloud_xyzi, size_t n, int n_scan,

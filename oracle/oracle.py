@@ -105,6 +105,10 @@ class Oracle:
         L.lo_transform_point_cloud.argtypes = [_f32p, C.c_size_t, _f32p, _f32p, C.c_int]
         L.lo_voxel_grid.argtypes = [_f32p, C.c_size_t, C.c_float, _f32p, C.POINTER(C.c_size_t)]
         L.lo_eigen3_sym.argtypes = [_f32p, _f32p, _f32p]
+        L.lo_range_image.argtypes = [C.POINTER(DeskewConfig), C.c_int, C.c_float, _f32p, _f32p, _f32p, _f32p,
+                                     np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS"), _f32p, C.c_size_t, C.c_double,
+                                     _f64p, _f64p, _f64p, _f64p, C.c_int, _f32p, _i32p, _i32p, _i32p, _f32p]
+        L.lo_range_image.restype = C.c_size_t
         L.lo_mark_occluded.argtypes = [_f32p, _i32p, C.c_size_t, _i32p]
         L.lo_extract_features.argtypes = [_f32p, C.c_size_t, C.c_int, _i32p, _i32p, _i32p, _f32p, C.c_float, C.c_float,
                                           C.c_float, _f32p, C.POINTER(C.c_size_t), _f32p, C.POINTER(C.c_size_t),
@@ -336,3 +340,18 @@ class Oracle:
             raise ValueError("ring index ranges outside [0, n-1]")
         return {"corner": corner[:nc.value].copy(), "surface": surf[:ns.value].copy(),
                 "curvature": curv[:n], "picked": picked[:n], "label": label[:n]}
+
+    # ---- extension: range-image build + cloudExtraction of upstream LIO-SAM (row A4) ----
+    def range_image(self, dcfg, horizon_scan, lidar_min_range, xyz, intensity, ring, time, t_cur, imu):
+        cur, T, RX, RY, RZ = imu
+        xyz = np.asarray(xyz, np.float32)
+        cells = int(dcfg.N_SCAN) * int(horizon_scan)
+        out = np.zeros((max(cells, 1), 4), np.float32)
+        start = np.zeros(dcfg.N_SCAN, np.int32); end = np.zeros(dcfg.N_SCAN, np.int32)
+        col = np.zeros(max(cells, 1), np.int32); rng = np.zeros(max(cells, 1), np.float32)
+        n = self.lib.lo_range_image(C.byref(dcfg), horizon_scan, lidar_min_range,
+                                    np.ascontiguousarray(xyz[:, 0]), np.ascontiguousarray(xyz[:, 1]), np.ascontiguousarray(xyz[:, 2]),
+                                    np.ascontiguousarray(intensity, np.float32), np.ascontiguousarray(ring, np.uint16),
+                                    np.ascontiguousarray(time, np.float32), len(xyz), t_cur, T, RX, RY, RZ, cur,
+                                    out.reshape(-1), start, end, col, rng)
+        return {"cloud": out[:n].copy(), "start_ring": start, "end_ring": end, "col": col[:n].copy(), "range": rng[:n].copy()}

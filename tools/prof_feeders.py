@@ -79,3 +79,9 @@ else:
             f = pkg.extract_features(*args)
         print(f"FE:67-77 smoothness + occlusion + feature selection + per-ring voxel 0.2 m: {len(z['org_cloud'])} points -> "
               f"{len(f['corner'])} corner, {len(f['surface'])} surface, {1e3 * (time.perf_counter() - t) / reps:.3f} ms/call incl. H2D+D2H")
+    ri = pkg.range_image(rec, t0, imu, N_SCAN=64, Horizon_SCAN=1800)
+    t = time.perf_counter()
+    for _ in range(reps):
+        ri = pkg.range_image(rec, t0, imu, N_SCAN=64, Horizon_SCAN=1800)
+    print(f"range image + cloudExtraction (extension): {len(rec)} -> {len(ri['cloud'])} points, "
+          f"{1e3 * (time.perf_counter() - t) / reps:.3f} ms/call incl. H2D+D2H")
