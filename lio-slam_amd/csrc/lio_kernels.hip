@@ -652,7 +652,8 @@ __constant__ int c_pair_a[32] = { 0,0,0,0,0,0, 1,1,1,1,1, 2,2,2,2, 3,3,3, 4,4, 5
 __constant__ int c_pair_b[32] = { 0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5, 4,5, 5,  6,6,6,6,6,6, 7, 0,0,0,0 };
 
 #ifndef LIO_MIN_WAVES
-#define LIO_MIN_WAVES 4      // waves per SIMD asked of the register allocator (<= 128 VGPRs)
+#define LIO_MIN_WAVES 5      // waves per SIMD asked of the register allocator for the default instantiation (<= 96 VGPRs, no scratch;
+                             // measured: 4 -> 5 is -6 % time, 6 spills and is 20 % slower); the other instantiations keep 4
 #endif
 #define LIO_LDS_PTS   2048     // staged map points per workgroup (32 KiB)
 #define LIO_LDS_CELLS 1536     // staged run offsets (6 KiB)
@@ -705,7 +706,7 @@ LIO_DEV void lio_arrive_and_finish(const LioIterParams& P, const LioBlockDesc& b
 // the corner map with the point-to-line association of upstream LIO-SAM; its rows join the same
 // per-scan sums (combineOptimizationCoeffs) through the partials of chunks n_surf_chunks.. .
 template <int PPT, bool STAGE, bool CORNER>
-__global__ __launch_bounds__(LIO_BLOCK, LIO_MIN_WAVES) void k_s2m_iterate(LioIterParams P)
+__global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MIN_WAVES : 4) void k_s2m_iterate(LioIterParams P)
 {
     __shared__ __attribute__((aligned(16))) double s_rows[LIO_BLOCK][8];  // [arz ary arx cx cy cz | -cw | accepted], widened once
     __shared__ double s_part[8][28];

@@ -452,10 +452,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
 
     // launch geometry: one workgroup = LIO_BLOCK * ppt consecutive points of one scan
     int ppt = h->cfg.kernel_variant;
-    if (ppt != 1 && ppt != 2 && ppt != 4) {
-        const size_t blocks1 = (total + LIO_BLOCK - 1) / LIO_BLOCK + (size_t)n_scans;
-        ppt = blocks1 > 16384 ? 4 : (blocks1 > 4096 ? 2 : 1);
-    }
+    if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 1;       // auto: one point per thread measured fastest at every batch size tried
     h->ppt = ppt;
     const size_t per_blk = (size_t)LIO_BLOCK * ppt;
     std::vector<LioBlockDesc>& blocks = h->v_blocks;
