@@ -324,8 +324,8 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": "k_s2m_iterate", "ms_per_launch": ms_per_launch,
-            "limiter": "not HBM: the per-lane candidate stream is bound by the CU's 64 B/clk L1 return path (~76 % busy) "
-                       "with VALU issue at ~60 %; see DESIGN.md section 6",
+            "limiter": "not HBM: the per-lane candidate stream is bound by divergent 16-byte load instructions through the "
+                       "texture addresser (~77 % busy) with VALU issue at ~60 %; see DESIGN.md section 6",
             "launches_per_step": int(live.sum()), "launches_per_graph_replay": int(args.graph), "algorithmic_bytes_per_launch": bytes_per_launch,
             "launch_ms": [round(float(v), 4) for v in lms], "launch_points": [int(v) for v in pts_per_launch],
         },
