@@ -36,6 +36,8 @@ def test_struct_layouts_match_c(pkg):
         printf("%zu %zu %zu %zu\n", sizeof(lio_s2m_config), sizeof(lio_s2m_result), sizeof(lio_s2m_profile), sizeof(lio_deskew_config));
         printf("%zu %zu %zu %zu\n", offsetof(lio_s2m_config, plane_tol), offsetof(lio_s2m_config, cell_div),
                offsetof(lio_s2m_result, pose_iter), offsetof(lio_s2m_profile, point_iters));
+        printf("%zu %zu %zu %zu\n", sizeof(lio_feature_config), sizeof(lio_range_image_config),
+               offsetof(lio_s2m_config, nn_cache), offsetof(lio_range_image_config, lidarMaxRange));
         return 0;
     }'''
     with tempfile.TemporaryDirectory() as d:
@@ -46,8 +48,10 @@ def test_struct_layouts_match_c(pkg):
         out = subprocess.check_output([exe], text=True).split()
     sizes = [int(v) for v in out]
     assert sizes[:4] == [C.sizeof(pkg.S2MConfig), C.sizeof(pkg.S2MResult), C.sizeof(pkg.S2MProfile), C.sizeof(pkg.DeskewConfig)]
-    assert sizes[4:] == [pkg.S2MConfig.plane_tol.offset, pkg.S2MConfig.cell_div.offset,
-                         pkg.S2MResult.pose_iter.offset, pkg.S2MProfile.point_iters.offset]
+    assert sizes[4:8] == [pkg.S2MConfig.plane_tol.offset, pkg.S2MConfig.cell_div.offset,
+                          pkg.S2MResult.pose_iter.offset, pkg.S2MProfile.point_iters.offset]
+    assert sizes[8:] == [C.sizeof(pkg.FeatureConfig), C.sizeof(pkg.RangeImageConfig),
+                         pkg.S2MConfig.nn_cache.offset, pkg.RangeImageConfig.lidarMaxRange.offset]
 
 
 def test_defaults_are_the_reference_literals(pkg):
