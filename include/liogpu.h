@@ -63,7 +63,7 @@ typedef struct lio_s2m_config {
     int32_t max_scan_pts;    /* hint: points per scan (buffers grow on demand; may be 0)    */
     int32_t record_corr_iter;/* iteration whose correspondences are kept for
                                 lio_s2m_get_correspondences (-1 = none)                    */
-    int32_t kernel_variant;  /* 0 = auto; >0 selects an association kernel (A/B testing)   */
+    int32_t kernel_variant;  /* scan points per thread: 0 = auto (1), or 1 / 2 / 4 (A/B testing)   */
     int32_t profile;         /* 1 = bracket every GN-iteration launch with HIP events      */
     int32_t lookahead;       /* GN launches enqueued ahead of the convergence check;
                                 0 = never enqueue an empty launch, -1 = auto               */
