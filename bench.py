@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--shard", choices=["map", "scan"], default="scan",
                     help="N>1: map = slabs of the map + halo, owner-computes (north_star); scan = map replicated, workgroups of every scan dealt round-robin")
     ap.add_argument("--nncache", type=int, default=1, help="1 = bound each point's search by its previous neighbours (exact)")
+    ap.add_argument("--maxsq", type=float, default=1.0, help="DIAGNOSTIC: squared 5-NN gate (reference: 1.0); smaller values shrink the "
+                    "searched neighbourhood and change the results -- only for timing what-if runs")
     ap.add_argument("--lawnmower", action="store_true", help="keyframes on a lawn-mower path inside a 50 m radius (configs[3])")
     args = ap.parse_args()
 
@@ -220,7 +222,7 @@ def main():
 
     # -------------------------------------------------------------- engine
     kcfg = dict(device_id=local_rank, profile=1, use_graph=1 if args.graph else 0, graph_iters=max(args.graph, 1), lookahead=args.lookahead, kernel_variant=args.variant,
-                use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch, nn_cache=args.nncache)
+                use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch, nn_cache=args.nncache, max_sq_dist=args.maxsq)
     if sharded:
         # the host runs `lookahead` GN iterations ahead of the convergence check (never 0 here: polling the
         # iteration just enqueued would drain the GPU once per iteration and sub-batch)
