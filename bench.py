@@ -193,27 +193,46 @@ def main():
     if not sharded:
         map_xyz, scans, poses0, poses_true = generate()
     else:
-        # rank 0 generates, everyone receives the SAME bytes (the ranks must agree on the map
-        # shards and on every convergence decision, or their collectives would not match)
-        if rank == 0:
-            map_xyz, scans, poses0, poses_true = generate()
-            lens = np.array([len(x) for x in scans], np.int64)
-            hdr = torch.tensor([len(map_xyz), int(lens.sum())], dtype=torch.int64, device="cuda")
-        else:
-            hdr = torch.zeros(2, dtype=torch.int64, device="cuda")
-        dist.broadcast(hdr, 0)
-        n_map, n_pts = int(hdr[0]), int(hdr[1])
-
-        def bcast(arr, shape, dtype):
-            t = torch.from_numpy(np.ascontiguousarray(arr)).cuda() if rank == 0 else torch.zeros(shape, dtype=dtype, device="cuda")
-            dist.broadcast(t, 0)
+        # Every rank ray-casts its own share of the scans on its own GPU (a query is the same whichever rank
+        # makes it); rank 0 also builds the map.  Then everyone receives the SAME bytes (the ranks must agree
+        # on the map shards and on every convergence decision, or their collectives would not match).
+        def bcast(arr, shape, dtype, src=0):
+            t = torch.from_numpy(np.ascontiguousarray(arr)).cuda() if rank == src else torch.zeros(shape, dtype=dtype, device="cuda")
+            dist.broadcast(t, src)
             return t.cpu().numpy()
 
-        map_xyz = bcast(map_xyz if rank == 0 else None, (n_map, 3), torch.float32)
-        cat = bcast(np.concatenate(scans) if rank == 0 else None, (n_pts, 3), torch.float32)
-        lens = bcast(lens if rank == 0 else None, (B,), torch.int64)
-        poses0 = bcast(poses0 if rank == 0 else None, (B, 6), torch.float32)
-        poses_true = bcast(poses_true if rank == 0 else None, (B, 6), torch.float32)
+        per = args.batch
+        if args.case_cache and os.path.exists(args.case_cache):
+            if rank == 0:
+                map_xyz, scans_all, poses0, poses_true = generate()
+            share = None
+        else:
+            case = synth.make_case(args.sensor, n_keyframes=args.keyframes, seed=synth.BASE_SEED, n_queries=B,
+                                   device=f"cuda:{local_rank}", lawnmower=args.lawnmower, q_range=(rank * per, (rank + 1) * per),
+                                   with_map=(rank == 0), progress=lambda k, n: log(f"map keyframe {k}/{n}"))
+            if rank == 0:
+                map_xyz = case["map"]
+                keyframes.extend(case["keyframes"])
+            share = [q for q in case["queries"] if q is not None]
+        hdr = torch.tensor([len(map_xyz) if rank == 0 else 0], dtype=torch.int64, device="cuda")
+        dist.broadcast(hdr, 0)
+        map_xyz = bcast(map_xyz if rank == 0 else None, (int(hdr[0]), 3), torch.float32)
+        if share is None:                                    # case cache: rank 0 holds everything
+            lens = bcast(np.array([len(x) for x in scans_all], np.int64) if rank == 0 else None, (B,), torch.int64)
+            cat = bcast(np.concatenate(scans_all) if rank == 0 else None, (int(lens.sum()), 3), torch.float32)
+            poses0 = bcast(poses0 if rank == 0 else None, (B, 6), torch.float32)
+            poses_true = bcast(poses_true if rank == 0 else None, (B, 6), torch.float32)
+        else:
+            lens_l, cats, p0s, pts = [], [], [], []
+            for r in range(world):                           # one broadcast round per rank's share
+                mine = rank == r
+                ln = bcast(np.array([len(q["scan"]) for q in share], np.int64) if mine else None, (per,), torch.int64, src=r)
+                cats.append(bcast(np.concatenate([q["scan"] for q in share]) if mine else None, (int(ln.sum()), 3), torch.float32, src=r))
+                p0s.append(bcast(np.stack([q["pose_init"] for q in share]).astype(np.float32) if mine else None, (per, 6), torch.float32, src=r))
+                pts.append(bcast(np.stack([q["pose_true"] for q in share]).astype(np.float32) if mine else None, (per, 6), torch.float32, src=r))
+                lens_l.append(ln)
+            lens, cat = np.concatenate(lens_l), np.concatenate(cats)
+            poses0, poses_true = np.concatenate(p0s), np.concatenate(pts)
         offs = np.concatenate([[0], np.cumsum(lens)])
         scans = [np.ascontiguousarray(cat[offs[i]:offs[i + 1]]) for i in range(B)]
     n_s = np.array([len(s) for s in scans])

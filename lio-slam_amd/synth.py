@@ -261,20 +261,27 @@ def make_query(boxes, true_pose, sensor="vlp16", seed=0, scan_leaf=0.4,
 
 
 def make_case(sensor="vlp16", n_keyframes=10, seed=BASE_SEED, kind="street", n_queries=1,
-              lawnmower=False, device=None, progress=None, sensor_override=None):
-    """One registration workload: map + n_queries (scan, true pose, initial guess)."""
+              lawnmower=False, device=None, progress=None, sensor_override=None, q_range=None, with_map=True):
+    """One registration workload: map + n_queries (scan, true pose, initial guess).
+
+    q_range=(a, b): only queries a..b-1 are ray-cast (the others are None) -- the ranks of a multi-GPU bench
+    each generate their share; every query is the same whichever rank makes it.  with_map=False skips the map."""
     sensor = sensor_override or sensor
     length = max(60.0, float(n_keyframes) + 20.0) if not lawnmower else 80.0
     boxes = make_scene(seed, length=length, kind=kind)
     kfs = keyframe_poses(n_keyframes, seed=seed, lawnmower=lawnmower)
     kept = []
-    map_xyz = build_map(boxes, kfs, sensor, seed=seed, device=device, progress=progress, keep=kept)
+    map_xyz = build_map(boxes, kfs, sensor, seed=seed, device=device, progress=progress, keep=kept) if with_map else None
     rng = np.random.Generator(np.random.MT19937(seed + 29))
+    # along the path, 0.5 m past a keyframe (the last one for q == 0); drawn for all queries up front
+    ks = [n_keyframes - 1 if q == 0 else int(rng.integers(0, n_keyframes)) for q in range(n_queries)]
+    a, b = q_range if q_range is not None else (0, n_queries)
     queries = []
     for q in range(n_queries):
-        # along the path, 0.5 m past a keyframe (the last one for q == 0)
-        k = n_keyframes - 1 if q == 0 else int(rng.integers(0, n_keyframes))
-        tp = np.array(kfs[k], np.float64)
+        if not (a <= q < b):
+            queries.append(None)
+            continue
+        tp = np.array(kfs[ks[q]], np.float64)
         tp[3] += 0.5 * math.cos(tp[2])
         tp[4] += 0.5 * math.sin(tp[2])
         scan, init = make_query(boxes, tp, sensor, seed=seed + 5000 + q, device=device)
