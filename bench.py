@@ -248,7 +248,7 @@ def main():
         kcfg_sh = dict(kcfg)
         kcfg_sh.pop("lookahead")
         runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2,
-                                     lookahead=max(args.lookahead, 2), **kcfg_sh)
+                                     lookahead=max(args.lookahead, int(os.environ.get("BENCH_SHARD_LAG", "2"))), **kcfg_sh)
         runner.upload(scans)
         s2m = runner.handles[0]
     else:

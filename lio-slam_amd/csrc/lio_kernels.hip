@@ -22,8 +22,7 @@
                               // same occupancy (0.144 vs 0.131 ms/launch) -- the loop is bound by the 64 B/clk L1 delivery of
                               // 1 KiB per wave-wide 16-byte load, not by latency; more loads in flight only queue up.
 #endif
-#define LIO_IDX_BITS 29
-#define LIO_IDX_MASK 0x1fffffff
+#define LIO_IDX_MASK 0x1fffffff      // index carried by the dummy records that pad the neighbourhood rows (never a winner)
 
 // ------------------------------------------------------------------ helpers
 LIO_DEV int lio_cell_coord(float v, float origin, float inv_cell, int n)

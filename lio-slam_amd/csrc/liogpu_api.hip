@@ -128,8 +128,8 @@ struct lio_s2m_handle {
     int graph_blocks_c = 0;
 
     // profiling
-    hipEvent_t ev_beg[LIO_MAX_ITERS], ev_end[LIO_MAX_ITERS], ev_chk[LIO_MAX_ITERS];
-    hipEvent_t ev_map[2];
+    hipEvent_t ev_beg[LIO_MAX_ITERS] = {}, ev_end[LIO_MAX_ITERS] = {}, ev_chk[LIO_MAX_ITERS] = {};
+    hipEvent_t ev_map[2] = {};
     int* h_active = nullptr;          // pinned: active-scan count after each launch
     bool ev_ok = false;
     lio_s2m_profile prof{};
@@ -186,6 +186,23 @@ static void lio_fill_consts(lio_s2m_handle* h)
     h->c.record_iter = g.record_corr_iter; h->c.min_scan_pts = g.min_scan_pts;
 }
 
+static int lio_s2m_init_resources(lio_s2m_handle* h)
+{
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i < LIO_MAX_ITERS; ++i) {
+        HIPCHK(hipEventCreate(&h->ev_beg[i]));
+        HIPCHK(hipEventCreate(&h->ev_end[i]));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_chk[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipHostMalloc((void**)&h->h_active, sizeof(int) * LIO_MAX_ITERS, hipHostMallocDefault));
+    HIPCHK(hipEventCreate(&h->ev_map[0]));
+    HIPCHK(hipEventCreate(&h->ev_map[1]));
+    h->ev_ok = true;
+    HIPCHK(hipMalloc((void**)&h->d_bbox, 6 * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void**)&h->d_active, sizeof(int)));
+    return LIO_OK;
+}
+
 extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
 {
     if (!cfg || !out) return lio_fail(LIO_ERR_ARG, "null argument");
@@ -205,18 +222,8 @@ extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
     }
     lio_fill_consts(h);
     h->shard.axis = -1;
-    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (int i = 0; i < LIO_MAX_ITERS; ++i) {
-        HIPCHK(hipEventCreate(&h->ev_beg[i]));
-        HIPCHK(hipEventCreate(&h->ev_end[i]));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_chk[i], hipEventDisableTiming));
-    }
-    HIPCHK(hipHostMalloc((void**)&h->h_active, sizeof(int) * LIO_MAX_ITERS, hipHostMallocDefault));
-    HIPCHK(hipEventCreate(&h->ev_map[0]));
-    HIPCHK(hipEventCreate(&h->ev_map[1]));
-    h->ev_ok = true;
-    HIPCHK(hipMalloc((void**)&h->d_bbox, 6 * sizeof(unsigned)));
-    HIPCHK(hipMalloc((void**)&h->d_active, sizeof(int)));
+    const int rc = lio_s2m_init_resources(h);
+    if (rc != LIO_OK) { lio_s2m_destroy(h); return rc; }    // (releases whatever had been created)
     *out = h;
     return LIO_OK;
 }
@@ -234,15 +241,15 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
                      h->d_nn_cache, h->d_summary };
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (h->ev_ok) {
-        for (int i = 0; i < LIO_MAX_ITERS; ++i) {
-            (void)hipEventDestroy(h->ev_beg[i]); (void)hipEventDestroy(h->ev_end[i]); (void)hipEventDestroy(h->ev_chk[i]);
-        }
-        if (h->h_active) (void)hipHostFree(h->h_active);
-        if (h->h_summary) (void)hipHostFree(h->h_summary);
-        (void)hipEventDestroy(h->ev_map[0]);
-        (void)hipEventDestroy(h->ev_map[1]);
+    for (int i = 0; i < LIO_MAX_ITERS; ++i) {               // (a handle whose creation failed half-way holds nulls)
+        if (h->ev_beg[i]) (void)hipEventDestroy(h->ev_beg[i]);
+        if (h->ev_end[i]) (void)hipEventDestroy(h->ev_end[i]);
+        if (h->ev_chk[i]) (void)hipEventDestroy(h->ev_chk[i]);
     }
+    if (h->h_active) (void)hipHostFree(h->h_active);
+    if (h->h_summary) (void)hipHostFree(h->h_summary);
+    if (h->ev_map[0]) (void)hipEventDestroy(h->ev_map[0]);
+    if (h->ev_map[1]) (void)hipEventDestroy(h->ev_map[1]);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
