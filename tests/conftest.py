@@ -26,7 +26,7 @@ def synth():
 @pytest.fixture(scope="session")
 def oracle():
     from oracle.oracle import Oracle, build
-    so = os.path.join(ROOT, "oracle", "liblio_oracle.so")
+    so = os.environ.get("LIO_ORACLE_LIB") or os.path.join(ROOT, "oracle", "liblio_oracle.so")   # e.g. an ASAN/UBSAN build
     if not os.path.exists(so):
         build(fast=False)
     return Oracle(so)
