@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--nncache", type=int, default=1, help="1 = bound each point's search by its previous neighbours (exact)")
     ap.add_argument("--maxsq", type=float, default=1.0, help="DIAGNOSTIC: squared 5-NN gate (reference: 1.0); smaller values shrink the "
                     "searched neighbourhood and change the results -- only for timing what-if runs")
+    ap.add_argument("--pipeline", type=int, default=0, help="0 = auto, 1 = fused k_s2m_iterate, 2 = split cert/scan/fit")
     ap.add_argument("--lawnmower", action="store_true", help="keyframes on a lawn-mower path inside a 50 m radius (configs[3])")
     args = ap.parse_args()
 
@@ -241,7 +242,7 @@ def main():
 
     # -------------------------------------------------------------- engine
     kcfg = dict(device_id=local_rank, profile=1, use_graph=1 if args.graph else 0, graph_iters=max(args.graph, 1), lookahead=args.lookahead, kernel_variant=args.variant,
-                use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch, nn_cache=args.nncache, max_sq_dist=args.maxsq)
+                use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch, nn_cache=args.nncache, max_sq_dist=args.maxsq, pipeline=args.pipeline)
     if sharded:
         # the host runs `lookahead` GN iterations ahead of the convergence check (never 0 here: polling the
         # iteration just enqueued would drain the GPU once per iteration and sub-batch)
@@ -381,6 +382,9 @@ def main():
             "launches_per_step": int(live.sum()), "launches_per_graph_replay": int(args.graph), "algorithmic_bytes_per_launch": bytes_per_launch,
             "launch_ms": [round(float(v), 4) for v in lms], "launch_points": [int(v) for v in pts_per_launch],
         },
+        "gn_pipeline": None if runner else {"kind": "split (k_s2m_cert + k_s2m_scan + k_s2m_fit per iteration)" if prof.pipeline == 2 else "fused (k_s2m_iterate)",
+                                            "points_per_iteration": [int(v) for v in prof.cert_points[:n_launch]],
+                                            "points_scanned_per_iteration": [int(v) for v in prof.scan_points[:n_launch]]},
         "map_build_ms": prof0.map_build_ms, "map_upload_ms": prof0.map_upload_ms,
         "grid_cells": int(prof0.n_cells),
     }

@@ -85,6 +85,9 @@ typedef struct lio_s2m_config {
     int32_t nn_cache;        /* 1 (default) = from the second GN iteration on, bound each point's
                                 search by the distances to its previous 5 neighbours (exact:
                                 the candidate run shrinks, the result does not change)      */
+    int32_t pipeline;        /* 0 / 1 = one fused launch per GN iteration (k_s2m_iterate); 2 = split: neighbour
+                                certificate / candidate scan / fit as three launches (identical results;
+                                measured slower on MI355X, kept as an option with its evidence)          */
 } lio_s2m_config;
 
 /* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in
@@ -113,6 +116,11 @@ typedef struct lio_s2m_profile {
     int64_t point_iters;       /* scan points processed by active scans over the run      */
     int64_t n_map;             /* resident map points                                     */
     int64_t n_cells;           /* grid cells                                              */
+    int32_t pipeline;          /* what the last run used: 1 = fused launches, 2 = split   */
+    int32_t pad_;
+    int64_t cert_points[LIO_MAX_ITERS]; /* split pipeline, per GN iteration: scan points looked at by the
+                                  neighbour certificate ...                               */
+    int64_t scan_points[LIO_MAX_ITERS]; /* ... and those that still needed a candidate scan */
 } lio_s2m_profile;
 
 typedef struct lio_s2m_handle lio_s2m_handle;

@@ -33,6 +33,7 @@ class S2MConfig(C.Structure):
         ("profile", C.c_int32), ("lookahead", C.c_int32), ("use_lds", C.c_int32), ("sort_scan", C.c_int32),
         ("cell_div", C.c_int32), ("xcd_remap", C.c_int32), ("tile_size", C.c_float),
         ("use_graph", C.c_int32), ("graph_iters", C.c_int32), ("sort_batch", C.c_int32), ("nn_cache", C.c_int32),
+        ("pipeline", C.c_int32),
     ]
 
 
@@ -53,6 +54,8 @@ class S2MProfile(C.Structure):
         ("launch_ms", C.c_float * LIO_MAX_ITERS), ("launch_active", C.c_int32 * LIO_MAX_ITERS),
         ("point_iters", C.c_int64),
         ("n_map", C.c_int64), ("n_cells", C.c_int64),
+        ("pipeline", C.c_int32), ("pad_", C.c_int32),
+        ("cert_points", C.c_int64 * LIO_MAX_ITERS), ("scan_points", C.c_int64 * LIO_MAX_ITERS),
     ]
 
 

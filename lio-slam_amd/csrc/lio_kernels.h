@@ -32,6 +32,23 @@ struct LioIterParams {
     long long* stamps;             // diagnostic phase clock: [block][wave][8] cycle counters, or null
 };
 
+// Arguments of the split pipeline's kernels: the fused kernel's plus the neighbour cache and the work list.
+struct LioSplitParams {
+    LioIterParams it;
+    // ---- split pipeline (cfg.pipeline): neighbour cache and the per-iteration scan work list
+    const LioGroupDesc* groups;    // certificate workgroups
+    int n_groups;
+    int* cache_idx;                // [total_pts][LIO_CACHE_K] map indices (caller order), nearest first after a scan / a certificate; -1 = none
+    float4* cache_q;               // [total_pts] (position the cache was built at, w = lower bound on the distance from
+                                   //  there to every map point NOT in the cache; w < 0: no cache)
+    int* pt_flag;                  // [total_pts] this iteration: 0 = no plane candidate, 1 = cache_idx[0..4] is the 5-NN (gate passed), 2 = scan pending
+    float* scan_bound2;            // [total_pts] squared search bound of a pending scan
+    int* scan_list;                // [total_pts] per group: slots with a pending scan, longest candidate run first
+    int* scan_cnt;                 // [n_groups]
+    int* stats;                    // [32][n_groups] diagnostics: candidate scans queued by each group in each GN iteration, or null
+    int sort_mode;                 // order of a group's work list (see k_s2m_cert)
+};
+
 void lio_launch_aos_to_soa(const void* src, size_t stride, int n, float* x, float* y, float* z,
                            float4* xyz4, hipStream_t s);
 void lio_launch_map_bbox(const float* x, const float* y, const float* z, int n, unsigned* bbox, hipStream_t s);
@@ -42,6 +59,7 @@ int  lio_scan_tiles(int n_cells);
 void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c,
                            int* n_active, hipStream_t s);
 void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s, bool corner = false);
+void lio_launch_split_iteration(const LioSplitParams& S, int n_blocks, hipStream_t s);
 void lio_launch_pack_summary(const LioScanState* st, int n_scans, float* out, hipStream_t s);
 void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
                       int* n_active, hipStream_t s);

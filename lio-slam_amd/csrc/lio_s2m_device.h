@@ -1,0 +1,417 @@
+// lio_s2m_device.h -- device code shared by the Gauss-Newton kernels of the scan-to-map path:
+// k_s2m_iterate (lio_kernels.hip, one fused launch per iteration) and k_s2m_cert / k_s2m_scan / k_s2m_fit
+// (lio_split.hip).  MO = /root/reference/src/liorf/src/mapOptmization.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "lio_types.h"
+#include "lio_device_math.h"
+#include "lio_kernels.h"
+
+// Map coordinates beyond this magnitude (or non-finite) are left out of the grid:
+// fp32 spacing there is > 1e7 m, they cannot be a neighbour within 1 m of anything,
+// and keeping them out keeps every squared distance finite.
+#define LIO_MAX_COORD 1.0e15f
+#ifndef LIO_PREFETCH
+#define LIO_PREFETCH 1        // candidate groups in flight ahead of the one being evaluated (1 or 2).  Measured: 2 is 10 % SLOWER at the
+                              // same occupancy (0.144 vs 0.131 ms/launch) -- the loop is bound by the 64 B/clk L1 delivery of
+                              // 1 KiB per wave-wide 16-byte load, not by latency; more loads in flight only queue up.
+#endif
+#define LIO_IDX_MASK 0x1fffffff      // index carried by the dummy records that pad the neighbourhood rows (never a winner)
+
+// ------------------------------------------------------------------ helpers
+LIO_DEV int lio_cell_coord(float v, float origin, float inv_cell, int n)
+{
+    // monotone in v; clamped to [-4, n+3] so that NaN / far-away queries land
+    // outside every neighbourhood instead of overflowing the int conversion
+    float c = floorf((v - origin) * inv_cell);
+    c = fminf(fmaxf(c, -4.0f), (float)(n + 3));
+    return (int)c;
+}
+
+// -------------------------------------------------------------- GN iterate
+// top-5 keys in the (d2, index) order of the exact k-NN (pcl::KdTreeFLANN::nearestKSearch MO:1631: ascending
+// squared distance; ties by the smaller map index), kept sorted with v_min_f64 / v_max_f64 only.
+LIO_DEV double lio_dmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+LIO_DEV double lio_dmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// Key = the bit pattern (d2 as fp32 in the high word, map index in the low word) read as a double.
+// d2 >= 0 and never NaN (map records and queries are finite, see the `act` test), so the high word is a
+// non-negative fp32 pattern: its top 11 bits are never 0x7ff, i.e. the double is finite, and finite
+// non-negative doubles order exactly like their bit patterns -- numeric order of the keys =
+// lexicographic (d2, index).  No conversion instruction, no index-width limit; d2 = 0 gives a
+// denormal double, which v_min_f64 / v_max_f64 keep (fp64 denormals are on in the kernel's FP mode).
+LIO_DEV double lio_make_key(float d2, int idx) { return __hiloint2double(__float_as_int(d2), idx); }
+LIO_DEV float lio_key_d2(double key) { return __int_as_float(__double2hiint(key)); }   // the squared distance, exactly
+LIO_DEV int lio_key_idx(double key) { return __double2loint(key); }
+
+struct LioTop5 { double k0, k1, k2, k3, k4; };
+
+LIO_DEV void lio_top5_insert(LioTop5& t, double x)
+{
+    double c;
+    c = lio_dmax(t.k0, x); t.k0 = lio_dmin(t.k0, x); x = c;
+    c = lio_dmax(t.k1, x); t.k1 = lio_dmin(t.k1, x); x = c;
+    c = lio_dmax(t.k2, x); t.k2 = lio_dmin(t.k2, x); x = c;
+    c = lio_dmax(t.k3, x); t.k3 = lio_dmin(t.k3, x); x = c;
+    t.k4 = lio_dmin(t.k4, x);
+}
+
+// Four candidates at once: sort the four new keys (5 compare-exchanges), take the element-wise minimum of
+// the sorted top-5 with the reversed new list (the five smallest of the nine, as an ascending-then-
+// descending sequence), and sort that with a 5-element bitonic merge (5 compare-exchanges): 24 min/max
+// operations instead of 4 x 9.  Same result as four single insertions (keys are distinct).
+#define LIO_CE_ASC(a, b) do { const double lo_ = lio_dmin(a, b); b = lio_dmax(a, b); a = lo_; } while (0)
+#define LIO_CE_DESC(a, b) do { const double hi_ = lio_dmax(a, b); b = lio_dmin(a, b); a = hi_; } while (0)
+LIO_DEV void lio_top5_insert4(LioTop5& t, double b0, double b1, double b2, double b3)
+{
+    LIO_CE_ASC(b0, b1); LIO_CE_ASC(b2, b3); LIO_CE_ASC(b0, b2); LIO_CE_ASC(b1, b3); LIO_CE_ASC(b1, b2);
+    double c0 = t.k0, c1 = lio_dmin(t.k1, b3), c2 = lio_dmin(t.k2, b2), c3 = lio_dmin(t.k3, b1), c4 = lio_dmin(t.k4, b0);
+    LIO_CE_DESC(c0, c4); LIO_CE_DESC(c0, c2); LIO_CE_DESC(c1, c3); LIO_CE_DESC(c0, c1); LIO_CE_DESC(c2, c3);
+    t.k0 = c4; t.k1 = c3; t.k2 = c2; t.k3 = c1; t.k4 = c0;
+}
+
+LIO_DEV void lio_top_insert4(LioTop5& t, double b0, double b1, double b2, double b3) { lio_top5_insert4(t, b0, b1, b2, b3); }
+
+// Top-8 (split pipeline, k_s2m_scan): the same scheme with eight keys -- sort the four new keys, element-wise
+// minimum of the upper half of the sorted top-8 with the reversed new list (the eight smallest of the twelve as a
+// bitonic sequence), 8-element bitonic merge: 5 + 12 compare-exchanges and 4 minima.
+struct LioTop8 { double k0, k1, k2, k3, k4, k5, k6, k7; };
+LIO_DEV void lio_top_insert4(LioTop8& t, double b0, double b1, double b2, double b3)
+{
+    LIO_CE_ASC(b0, b1); LIO_CE_ASC(b2, b3); LIO_CE_ASC(b0, b2); LIO_CE_ASC(b1, b3); LIO_CE_ASC(b1, b2);
+    double c0 = t.k0, c1 = t.k1, c2 = t.k2, c3 = t.k3;
+    double c4 = lio_dmin(t.k4, b3), c5 = lio_dmin(t.k5, b2), c6 = lio_dmin(t.k6, b1), c7 = lio_dmin(t.k7, b0);
+    LIO_CE_ASC(c0, c4); LIO_CE_ASC(c1, c5); LIO_CE_ASC(c2, c6); LIO_CE_ASC(c3, c7);
+    LIO_CE_ASC(c0, c2); LIO_CE_ASC(c1, c3); LIO_CE_ASC(c4, c6); LIO_CE_ASC(c5, c7);
+    LIO_CE_ASC(c0, c1); LIO_CE_ASC(c2, c3); LIO_CE_ASC(c4, c5); LIO_CE_ASC(c6, c7);
+    t.k0 = c0; t.k1 = c1; t.k2 = c2; t.k3 = c3; t.k4 = c4; t.k5 = c5; t.k6 = c6; t.k7 = c7;
+}
+
+// Eight keys in ascending order (19 compare-exchanges, the optimal 8-input network).
+LIO_DEV void lio_sort8(double& a0, double& a1, double& a2, double& a3, double& a4, double& a5, double& a6, double& a7)
+{
+    LIO_CE_ASC(a0, a1); LIO_CE_ASC(a2, a3); LIO_CE_ASC(a4, a5); LIO_CE_ASC(a6, a7);
+    LIO_CE_ASC(a0, a2); LIO_CE_ASC(a1, a3); LIO_CE_ASC(a4, a6); LIO_CE_ASC(a5, a7);
+    LIO_CE_ASC(a1, a2); LIO_CE_ASC(a5, a6); LIO_CE_ASC(a0, a4); LIO_CE_ASC(a3, a7);
+    LIO_CE_ASC(a1, a5); LIO_CE_ASC(a2, a6);
+    LIO_CE_ASC(a1, a4); LIO_CE_ASC(a3, a6);
+    LIO_CE_ASC(a2, a4); LIO_CE_ASC(a3, a5);
+    LIO_CE_ASC(a3, a4);
+}
+
+// FLANN L2_Simple: ((dx*dx) + dy*dy) + dz*dz, accumulated from 0
+LIO_DEV float lio_sqdist(float ax, float ay, float az, float bx, float by, float bz)
+{
+    float r = 0.0f, d;
+    d = ax - bx; r += d * d;
+    d = ay - by; r += d * d;
+    d = az - bz; r += d * d;
+    return r;
+}
+
+// The serial Gauss-Newton step of one scan: LMOptimization MO:1702-1837 from
+// the reduced sums onward, plus the loop control of scan2MapOptimization
+// MO:1848-1859.  One lane; `ws` is LDS (or any) working storage.
+__device__ static void lio_gn_step(LioScanState* st, const double* sums, const LioConsts& c, LioSolveWs* ws,
+                                   int* n_active, int lane)
+{
+    // Called by ALL lanes of one wave.  Lane 0 carries the serial algorithm; the eigen-decomposition and the
+    // 6x6 product of the first iteration are spread over the wave (lio_eigen6_sym_wave, lio_gemm6_wave).
+    const int it = st->iter;
+    const int nc = (int)sums[LIO_SUM_NC];
+    const bool solve = nc >= c.min_corr;                       // MO:1721-1724 (wave-uniform)
+    float pose[6];
+    bool conv = false;
+    if (lane == 0) {
+        for (int k = 0; k < 6; ++k) pose[k] = st->pose[k];
+        st->n_corr_last = nc;
+        if (it < 32) st->n_corr_iter[it] = nc;
+    }
+
+    if (solve) {
+        int deg = 0;
+        if (lane == 0) {
+            deg = st->is_degenerate;
+            int p = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int b = a; b < 6; ++b) {
+                    const float v = (float)sums[p++];
+                    ws->AtA[a * 6 + b] = v; ws->AtA[b * 6 + a] = v;
+                }
+            for (int a = 0; a < 6; ++a) ws->AtB[a] = (float)sums[21 + a];
+            for (int k = 0; k < 36; ++k) { st->AtA[k] = ws->AtA[k]; ws->A[k] = ws->AtA[k]; }
+            for (int k = 0; k < 6; ++k) { st->AtB[k] = ws->AtB[k]; ws->X[k] = ws->AtB[k]; }
+
+            lio_solve6_qr(ws->A, ws->X, ws->vl, ws->hf);       // MO:1784
+        }
+        LIO_LDS_FENCE();
+        const float* matP = st->matP;
+        if (it == 0) {                                         // MO:1786-1808
+            if (lane < 36) ws->A[lane] = ws->AtA[lane];
+            LIO_LDS_FENCE();
+            lio_eigen6_sym_wave(ws->A, ws->W, ws->V, ws->indR, ws->indC, lane);   // cv::eigen, MO:1792
+            if (lane == 0) {
+                for (int k = 0; k < 36; ++k) ws->V2[k] = ws->V[k];
+                deg = 0;
+                for (int i = 5; i >= 0; --i) {
+                    if (ws->W[i] < c.eig_thresh) {
+                        for (int j = 0; j < 6; ++j) ws->V2[i * 6 + j] = 0;
+                        deg = 1;
+                    } else {
+                        break;
+                    }
+                }
+                for (int k = 0; k < 36; ++k) ws->A[k] = ws->V[k];
+                lio_inv6_lu(ws->A, ws->B);
+                st->is_degenerate = deg;
+            }
+            LIO_LDS_FENCE();
+            lio_gemm6_wave(ws->B, ws->V2, ws->A, lane);        // matP = matV.inv() * matV2, MO:1807
+            LIO_LDS_FENCE();
+            if (lane < 36) st->matP[lane] = ws->A[lane];
+            matP = ws->A;
+        }
+        if (lane == 0) {
+            if (deg) {                                         // MO:1810-1815
+                for (int k = 0; k < 6; ++k) ws->X2[k] = ws->X[k];
+                lio_gemm32f(matP, ws->X2, ws->X, 6, 6, 1);
+            }
+            for (int k = 0; k < 6; ++k) pose[k] += ws->X[k];   // MO:1817-1822
+
+            // MO:1824-1831: rad2deg in float, squares/sqrt in double, stored as float
+            const double r0 = (double)(ws->X[0] * 57.29578f), r1 = (double)(ws->X[1] * 57.29578f), r2 = (double)(ws->X[2] * 57.29578f);
+            const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+            const double t0 = (double)(ws->X[3] * 100), t1 = (double)(ws->X[4] * 100), t2 = (double)(ws->X[5] * 100);
+            const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+            conv = ((double)deltaR < c.conv_deg) && ((double)deltaT < c.conv_cm);   // MO:1833
+        }
+    }
+    if (lane != 0) return;
+
+    for (int k = 0; k < 6; ++k) st->pose[k] = pose[k];
+    if (it < 32) for (int k = 0; k < 6; ++k) st->pose_iter[it][k] = pose[k];
+    int iters = it + 1;
+    int done = 0;
+    if (conv) { st->converged = 1; if (!c.force_all) done = 1; }   // MO:1857-1858
+    if (iters >= c.max_iters) done = 1;                            // MO:1848
+    if (nc < c.min_corr && !done) {
+        // LMOptimization returned false WITHOUT touching the pose (MO:1721-1724):
+        // every remaining iteration would redo identical work.  Fast-forward.
+        for (int k = iters; k < c.max_iters && k < 32; ++k) {
+            st->n_corr_iter[k] = nc;
+            for (int j = 0; j < 6; ++j) st->pose_iter[k][j] = pose[j];
+        }
+        iters = c.max_iters;
+        done = 1;
+    }
+    st->iter = iters;
+    st->done = done;
+    st->status = (nc < c.min_corr) ? 2 : 0;
+    if (done && n_active) atomicSub(n_active, 1);
+    if (!done) {
+        for (int k = 0; k < 12; ++k) st->Tp[k] = st->T[k];         // (search bound of the next pass, see k_s2m_iterate)
+        lio_pose_to_transform(pose, st->T, st->trig);              // MO:1613-1616 for the next pass
+    }
+}
+
+// ---- candidate scan, global-memory form -----------------------------------
+// One contiguous run of the replicated neighbourhood row (see k_map_nbr_*), walked in ALIGNED
+// groups of four records (64 B) with the next group already in flight.  Aligning the group
+// boundaries may pull in up to three records before and after the run: they are other map points
+// of the SAME row list (row lists are 4-aligned and padded with far-away dummies, see
+// k_map_nbr_pad_rows), i.e. a duplicate-free superset of the neighbourhood, which keeps the
+// search exact and needs no predication.  Two candidates are
+// evaluated per VALU op (v_pk_add_f32 / v_pk_mul_f32 on the pair-transposed records).
+typedef float lio_f2 __attribute__((ext_vector_type(2)));
+
+LIO_DEV void lio_knn_pair(const float4& a, const float4& b, lio_f2 qx, lio_f2 qy, lio_f2 qz, double& k0, double& k1)
+{
+    const lio_f2 X = { a.x, a.y }, Y = { a.z, a.w }, Z = { b.x, b.y };
+    const lio_f2 dx = X - qx, dy = Y - qy, dz = Z - qz;
+    // FLANN L2_Simple per candidate: ((dx*dx) + dy*dy) + dz*dz
+    const lio_f2 d2 = (dx * dx + dy * dy) + dz * dz;
+    k0 = lio_make_key(d2.x, __float_as_int(b.z));
+    k1 = lio_make_key(d2.y, __float_as_int(b.w));
+}
+
+LIO_DEV void lio_knn_group(const float4& c0, const float4& c1, const float4& c2, const float4& c3,
+                           lio_f2 qx, lio_f2 qy, lio_f2 qz, LioTop5& top)
+{
+    double k0, k1, k2, k3;
+    lio_knn_pair(c0, c1, qx, qy, qz, k0, k1);
+    lio_knn_pair(c2, c3, qx, qy, qz, k2, k3);
+    lio_top5_insert4(top, k0, k1, k2, k3);
+}
+
+LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
+                            int cx, int cy, int cz, int xlo, int xhi, LioTop5& top)
+{
+    // [xlo, xhi]: x-cells that can hold a point closer than the current bound (the whole +-k range
+    // unless the previous iteration's neighbours gave a tighter one, see "neighbour cache" below)
+    const int x0 = max(max(cx - g.k, 0), xlo), x1 = min(min(cx + g.k, g.nx - 1), xhi);
+    if (x0 > x1) return;
+    const int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nx;
+    const unsigned beg = (unsigned)P.nbr_start[row + x0] & ~3u;
+    const unsigned end = (unsigned)P.nbr_start[row + x1 + 1];
+    if (beg >= end) return;
+    const lio_f2 QX = { qx, qx }, QY = { qy, qy }, QZ = { qz, qz };
+    const float4* p = P.nbr_pts + beg;                     // float4 index == record index (2 float4 per pair)
+#if LIO_PREFETCH == 2
+    // two groups in flight (the table is padded, reading up to two groups past a run is harmless)
+    float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+    float4 n0 = p[4], n1 = p[5], n2 = p[6], n3 = p[7];
+    for (unsigned j = beg;;) {
+        float4 f0 = n0, f1 = n1, f2 = n2, f3 = n3;
+        if (j + 8 < end) { f0 = p[8]; f1 = p[9]; f2 = p[10]; f3 = p[11]; }
+        lio_knn_group(c0, c1, c2, c3, QX, QY, QZ, top);
+        j += 4;
+        if (j >= end) break;
+        p += 4;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        n0 = f0; n1 = f1; n2 = f2; n3 = f3;
+    }
+#else
+    float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+    for (unsigned j = beg + 4; j < end; j += 4) {
+        p += 4;
+        const float4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3];
+        lio_knn_group(c0, c1, c2, c3, QX, QY, QZ, top);
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+    lio_knn_group(c0, c1, c2, c3, QX, QY, QZ, top);
+#endif
+}
+
+// the same walk keeping the eight nearest (k_s2m_scan)
+LIO_DEV void lio_knn_group8(const float4& c0, const float4& c1, const float4& c2, const float4& c3,
+                           lio_f2 qx, lio_f2 qy, lio_f2 qz, LioTop8& top)
+{
+    double k0, k1, k2, k3;
+    lio_knn_pair(c0, c1, qx, qy, qz, k0, k1);
+    lio_knn_pair(c2, c3, qx, qy, qz, k2, k3);
+    lio_top_insert4(top, k0, k1, k2, k3);
+}
+
+LIO_DEV void lio_knn_global8(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
+                            int cx, int cy, int cz, int xlo, int xhi, LioTop8& top)
+{
+    // [xlo, xhi]: x-cells that can hold a point closer than the current bound (the whole +-k range
+    // unless the previous iteration's neighbours gave a tighter one, see "neighbour cache" below)
+    const int x0 = max(max(cx - g.k, 0), xlo), x1 = min(min(cx + g.k, g.nx - 1), xhi);
+    if (x0 > x1) return;
+    const int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nx;
+    const unsigned beg = (unsigned)P.nbr_start[row + x0] & ~3u;
+    const unsigned end = (unsigned)P.nbr_start[row + x1 + 1];
+    if (beg >= end) return;
+    const lio_f2 QX = { qx, qx }, QY = { qy, qy }, QZ = { qz, qz };
+    const float4* p = P.nbr_pts + beg;                     // float4 index == record index (2 float4 per pair)
+#if LIO_PREFETCH == 2
+    // two groups in flight (the table is padded, reading up to two groups past a run is harmless)
+    float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+    float4 n0 = p[4], n1 = p[5], n2 = p[6], n3 = p[7];
+    for (unsigned j = beg;;) {
+        float4 f0 = n0, f1 = n1, f2 = n2, f3 = n3;
+        if (j + 8 < end) { f0 = p[8]; f1 = p[9]; f2 = p[10]; f3 = p[11]; }
+        lio_knn_group8(c0, c1, c2, c3, QX, QY, QZ, top);
+        j += 4;
+        if (j >= end) break;
+        p += 4;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        n0 = f0; n1 = f1; n2 = f2; n3 = f3;
+    }
+#else
+    float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+    for (unsigned j = beg + 4; j < end; j += 4) {
+        p += 4;
+        const float4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3];
+        lio_knn_group8(c0, c1, c2, c3, QX, QY, QZ, top);
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+    lio_knn_group8(c0, c1, c2, c3, QX, QY, QZ, top);
+#endif
+}
+
+// Association of one scan point from its five nearest map points (indices into the caller's map order):
+// surfOptimization MO:1642-1683 -- plane through the neighbours, plane test, weight, coefficients -- or, for
+// the CORNER extension, the point-to-line form of upstream LIO-SAM.  Returns "accepted" (MO:1679).
+template <bool CORNER>
+LIO_DEV bool lio_assoc_point(const LioIterParams& P, const int nn[5], float qx, float qy, float qz,
+                             float px, float py, float pz, float& cxx, float& cyy, float& czz, float& cww)
+{
+    bool accept = false;
+    // MO:1642-1646: neighbours in the caller's map order (original xyz)
+    float a[5][3], m[5][3];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float4 mp = P.map_xyz4[nn[j]];
+        m[j][0] = a[j][0] = mp.x;
+        m[j][1] = a[j][1] = mp.y;
+        m[j][2] = a[j][2] = mp.z;
+    }
+    if (CORNER) {
+        accept = lio_corner_assoc(m, qx, qy, qz, P.c.weight, P.c.min_s, cxx, cyy, czz, cww);
+    } else {
+        float X0[3];
+        lio_plane_qr5x3(a, X0);                                  // MO:1648
+        float pa = X0[0], pb = X0[1], pc = X0[2], pd = 1;         // MO:1650-1653
+        const float ps = sqrtf(pa * pa + pb * pb + pc * pc);      // MO:1655
+        pa /= ps; pb /= ps; pc /= ps; pd /= ps;                   // MO:1656
+        bool planeValid = true;                                   // MO:1658-1666
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const float v = fabsf(pa * m[j][0] + pb * m[j][1] + pc * m[j][2] + pd);
+            if ((double)v > P.c.plane_tol) planeValid = false;
+        }
+        if (planeValid) {
+            const float pd2 = pa * qx + pb * qy + pc * qz + pd;   // MO:1669
+            const float r2 = px * px + py * py + pz * pz;
+            // MO:1671-1672 (product, quotient and difference in double)
+            const float s = (float)(1 - P.c.weight * (double)fabsf(pd2) / (double)sqrtf(sqrtf(r2)));
+            cxx = s * pa; cyy = s * pb; czz = s * pc; cww = s * pd2;   // MO:1674-1677
+            accept = (double)s > P.c.min_s;                       // MO:1679
+        }
+    }
+    return accept;
+}
+
+// (a, b) column pair of each of the 28 sums: 21 upper-triangle JtJ, 6 Jtr, N_c
+static __constant__ int c_pair_a[32] = { 0,0,0,0,0,0, 1,1,1,1,1, 2,2,2,2, 3,3,3, 4,4, 5,  0,1,2,3,4,5, 7, 0,0,0,0 };
+static __constant__ int c_pair_b[32] = { 0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5, 4,5, 5,  6,6,6,6,6,6, 7, 0,0,0,0 };
+
+// Tail of an association workgroup, executed by its wave 0 after the partial sums were stored
+// write-through: drain, arrive on the scan's counter; the workgroup whose arrival is last adds up
+// the scan's partials in workgroup order and runs the Gauss-Newton step (or publishes the sums).
+LIO_DEV void lio_arrive_and_finish(const LioIterParams& P, const LioBlockDesc& bd, LioScanState* st, int lane,
+                                   double* s_sum, LioSolveWs* s_ws, long long* stamp)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last = 0;
+    if (lane == 0) {
+        const unsigned old = atomicAdd(&P.arrive[bd.scan], 1u);
+        last = (old == (unsigned)bd.n_blk - 1u);
+    }
+    last = __shfl(last, 0);
+    if (stamp && lane == 0) stamp[6] = (long long)__builtin_readcyclecounter();
+    if (!last) return;
+
+    // last workgroup of this scan: fixed-order sum over the scan's chunks
+    if (lane < 28) {
+        const double* base_p = P.partials + (size_t)bd.scan * P.max_blk * LIO_SUMS + lane;
+        double v = 0.0;
+        for (int b = 0; b < bd.n_blk; b += 8) {          // 8 write-through loads in flight, summed in chunk order
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                t[u] = __hip_atomic_load(base_p + (size_t)min(b + u, bd.n_blk - 1) * LIO_SUMS,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += (b + u < bd.n_blk) ? t[u] : 0.0;
+        }
+        s_sum[lane] = v;
+        if (P.sums_out) P.sums_out[(size_t)bd.scan * LIO_SUMS + lane] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave: the sums are in LDS before anyone reads them
+    if (lane == 0) P.arrive[bd.scan] = 0;                  // re-arm for the next launch
+    if (!P.sums_out) lio_gn_step(st, s_sum, P.c, s_ws, P.n_active, lane);
+}
+

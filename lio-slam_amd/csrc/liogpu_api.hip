@@ -16,6 +16,7 @@
 #include <mutex>
 #include <algorithm>
 
+
 static thread_local std::string g_last_error;
 
 static int lio_fail(int code, const char* what, hipError_t e = hipSuccess)
@@ -99,6 +100,18 @@ struct lio_s2m_handle {
     bool sorted = false;
     float* d_nn_cache = nullptr; size_t cap_nn_cache = 0;   // [total_pts] squared 5th-neighbour distance of the previous GN iteration
     long long* d_stamps = nullptr; size_t cap_stamps = 0;
+    // split pipeline (cfg.pipeline): neighbour cache + per-iteration scan work list
+    bool split = false;               // the resident batch runs k_s2m_cert / _scan / _fit instead of k_s2m_iterate
+    bool cache_dirty = true;          // map or batch changed: the neighbour cache must be dropped before the next run
+    std::vector<LioGroupDesc> v_groups;
+    LioGroupDesc* d_groups = nullptr; size_t cap_groups = 0;
+    int* d_cache_idx = nullptr; size_t cap_cache_idx = 0;
+    float4* d_cache_q = nullptr; size_t cap_cache_q = 0;
+    int* d_pt_flag = nullptr; size_t cap_pt_flag = 0;
+    float* d_scan_bound2 = nullptr; size_t cap_scan_bound2 = 0;
+    int* d_scan_list = nullptr; size_t cap_scan_list = 0;
+    int* d_scan_cnt = nullptr; size_t cap_scan_cnt = 0;
+    int* d_split_stats = nullptr; size_t cap_split_stats = 0;      // [32][n_groups]
     // hipGraph-captured chunk of GN iterations (cfg.use_graph)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -173,6 +186,7 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->graph_iters = 4;
     c->sort_scan = 1;
     c->nn_cache = 1;
+    c->pipeline = 0;
 }
 
 static void lio_fill_consts(lio_s2m_handle* h)
@@ -239,7 +253,8 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_state, h->d_poses, h->d_blocks, h->d_partials, h->d_arrive, h->d_rec_flag,
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
                      h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
-                     h->d_nn_cache, h->d_summary };
+                     h->d_nn_cache, h->d_summary, h->d_groups, h->d_cache_idx, h->d_cache_q, h->d_pt_flag,
+                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < LIO_MAX_ITERS; ++i) {               // (a handle whose creation failed half-way holds nulls)
         if (h->ev_beg[i]) (void)hipEventDestroy(h->ev_beg[i]);
@@ -352,6 +367,7 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
     h->n_map = n;
     h->has_map = true;
     h->graph_dirty = true;
+    h->cache_dirty = true;            // cached neighbour indices refer to the previous map
     return LIO_OK;
 }
 
@@ -423,6 +439,36 @@ extern "C" int lio_s2m_set_shard(lio_s2m_handle* h, int32_t axis, int32_t lo, in
     return LIO_OK;
 }
 
+// Certificate workgroups of the split pipeline: up to LIO_GROUP_BLOCKS consecutive association chunks of
+// one scan, in the order of the (possibly re-ordered) workgroup list.
+static int lio_build_groups(lio_s2m_handle* h, const std::vector<LioBlockDesc>& blocks)
+{
+    std::vector<LioGroupDesc>& gr = h->v_groups;
+    gr.clear();
+    for (size_t i = 0; i < blocks.size();) {
+        const LioBlockDesc& b0 = blocks[i];
+        const LioScanState& st = h->h_state[b0.scan];
+        size_t j = i + 1;
+        while (j < blocks.size() && j - i < LIO_GROUP_BLOCKS && blocks[j].scan == b0.scan &&
+               blocks[j].first == blocks[j - 1].first + LIO_BLOCK)
+            ++j;
+        const int last = blocks[j - 1].first + LIO_BLOCK;
+        LioGroupDesc g;
+        g.scan = b0.scan;
+        g.first = b0.first;
+        g.n = (last < st.n_pts ? last : st.n_pts) - b0.first;
+        g.list_base = st.offset + b0.first;
+        gr.push_back(g);
+        i = j;
+    }
+    HIPCHK(lio_grow(&h->d_groups, &h->cap_groups, gr.size() ? gr.size() : 1));
+    HIPCHK(lio_grow(&h->d_scan_cnt, &h->cap_scan_cnt, gr.size() ? gr.size() : 1));
+    if (h->cfg.profile) HIPCHK(lio_grow(&h->d_split_stats, &h->cap_split_stats, (gr.size() ? gr.size() : 1) * LIO_MAX_ITERS));
+    if (!gr.empty())
+        HIPCHK(hipMemcpyAsync(h->d_groups, gr.data(), gr.size() * sizeof(LioGroupDesc), hipMemcpyHostToDevice, h->stream));
+    return LIO_OK;
+}
+
 // ------------------------------------------------------------------- batch
 extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const void* const* scans,
                                     const size_t* n_pts, size_t stride)
@@ -461,6 +507,18 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     int ppt = h->cfg.kernel_variant;
     if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 1;       // auto: one point per thread measured fastest at every batch size tried
     h->ppt = ppt;
+    // split pipeline (opt-in, cfg.pipeline = 2): neighbour certificate + candidate scan + fit as three launches
+    // (lio_split.hip).  Bit-identical, and measured SLOWER than the fused launch on an MI355X (DESIGN.md section 6:
+    // 2.2 ms vs 1.5 ms of kernel time per 512-scan step), so auto (0) means fused.
+    h->split = ppt == 1 && !h->cfg.use_lds && h->cfg.profile != 2 && h->cfg.pipeline == 2;
+    if (h->split) {
+        HIPCHK(lio_grow(&h->d_cache_idx, &h->cap_cache_idx, tt * LIO_CACHE_K));
+        HIPCHK(lio_grow(&h->d_cache_q, &h->cap_cache_q, tt));
+        HIPCHK(lio_grow(&h->d_pt_flag, &h->cap_pt_flag, tt));
+        HIPCHK(lio_grow(&h->d_scan_bound2, &h->cap_scan_bound2, tt));
+        HIPCHK(lio_grow(&h->d_scan_list, &h->cap_scan_list, tt));
+    }
+    h->cache_dirty = true;
     const size_t per_blk = (size_t)LIO_BLOCK * ppt;
     std::vector<LioBlockDesc>& blocks = h->v_blocks;
     blocks.clear();
@@ -516,6 +574,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     if (!blocks.empty())
         HIPCHK(hipMemcpyAsync(h->d_blocks, blocks.data(), blocks.size() * sizeof(LioBlockDesc),
                               hipMemcpyHostToDevice, h->stream));
+    if (h->split) { const int rcg = lio_build_groups(h, blocks); if (rcg != LIO_OK) return rcg; }
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state.data(), (size_t)n_scans * sizeof(LioScanState),
                           hipMemcpyHostToDevice, h->stream));
     std::vector<LioScanTiles>& tiles = h->v_tiles;
@@ -593,6 +652,7 @@ extern "C" int lio_s2m_set_corner_map(lio_s2m_handle* h, const void* pts, size_t
         cc.use_lds = 0;
         cc.profile = 0;
         cc.use_graph = 0;
+        cc.pipeline = 1;               // the edge launch is the fused kernel's CORNER instantiation
         int rc = lio_s2m_create(&cc, &h->corner);
         if (rc != LIO_OK) return rc;
         if ((rc = lio_s2m_set_stream(h->corner, h->stream)) != LIO_OK) return rc;
@@ -694,6 +754,7 @@ extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
             for (int i = h->v_first_orig[s]; i < h->v_first_orig[s + 1]; ++i) sorted.push_back(h->v_blocks[i]);
         }
         HIPCHK(hipMemcpyAsync(h->d_blocks, sorted.data(), sorted.size() * sizeof(LioBlockDesc), hipMemcpyHostToDevice, h->stream));
+        if (h->split) { const int rcg = lio_build_groups(h, sorted); if (rcg != LIO_OK) return rcg; }
     }
     if (!h->defer_sync) HIPCHK(hipStreamSynchronize(h->stream));
     h->poses_set = true;
@@ -744,6 +805,23 @@ static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_ou
     P.d5_cache = (h->cfg.nn_cache && !h->cfg.use_lds) ? h->d_nn_cache : nullptr;
 }
 
+static void lio_fill_split(lio_s2m_handle* h, const LioIterParams& P, LioSplitParams& S)
+{
+    memset(&S, 0, sizeof(S));
+    S.it = P;
+    S.groups = h->d_groups;
+    S.n_groups = (int)h->v_groups.size();
+    S.cache_idx = h->d_cache_idx;
+    S.cache_q = h->d_cache_q;
+    S.pt_flag = h->d_pt_flag;
+    S.scan_bound2 = h->d_scan_bound2;
+    S.scan_list = h->d_scan_list;
+    S.scan_cnt = h->d_scan_cnt;
+    S.stats = h->cfg.profile ? h->d_split_stats : nullptr;
+    const char* sm = getenv("LIO_SPLIT_SORT");
+    S.sort_mode = sm ? atoi(sm) : 0;      // measured: 0 (as they come) 246 us, 1 (by run length) 302 us, 2 (per chunk) 249 us for the first scan launch
+}
+
 // Arguments of the corner launch: the child's map, grid, edge points and workgroup list; everything
 // that is per scan (state, partial sums, arrival counters, active count) is the parent's.
 static void lio_fill_params_corner(lio_s2m_handle* h, LioIterParams& Pc, double* sums_out)
@@ -764,7 +842,13 @@ static void lio_fill_params_corner(lio_s2m_handle* h, LioIterParams& Pc, double*
 static void lio_launch_gn(lio_s2m_handle* h, const LioIterParams& P, const LioIterParams* Pc)
 {
     if (Pc) lio_launch_iterate(*Pc, h->corner->n_blocks, 1, false, h->stream, true);
-    lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
+    if (h->split) {
+        LioSplitParams S;
+        lio_fill_split(h, P, S);
+        lio_launch_split_iteration(S, h->n_blocks, h->stream);
+    } else {
+        lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
+    }
 }
 
 extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
@@ -775,6 +859,13 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->c, h->d_active, h->stream);
+    if (h->split && h->cfg.profile && h->d_split_stats)
+        HIPCHK(hipMemsetAsync(h->d_split_stats, 0, h->v_groups.size() * LIO_MAX_ITERS * sizeof(int), h->stream));
+    if (h->split && h->cache_dirty) {
+        // 0xff bytes = NaN in the bound word: "no cache" (the `>= 0` test fails)
+        HIPCHK(hipMemsetAsync(h->d_cache_q, 0xff, (h->total_pts ? h->total_pts : 1) * sizeof(float4), h->stream));
+        h->cache_dirty = false;
+    }
     // search-bound cache: iteration 0 never reads it and rewrites the entry of every point it processes; entries
     // of points it does not process (owned by another rank) could date from an earlier run -> drop them
     // (0xff bytes = NaN, which fails the `>= 0` validity test like -1 does)
@@ -1012,6 +1103,25 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
     }
     h->prof.n_units = n_units;
     h->prof.unit_iters = h->unit_iters;
+    h->prof.pipeline = h->split ? 2 : 1;
+    memset(h->prof.cert_points, 0, sizeof(h->prof.cert_points));
+    memset(h->prof.scan_points, 0, sizeof(h->prof.scan_points));
+    if (h->split && h->cfg.profile && h->d_split_stats && !h->v_groups.empty()) {
+        const size_t ng = h->v_groups.size();
+        std::vector<int> stt(ng * LIO_MAX_ITERS);
+        HIPCHK(hipMemcpy(stt.data(), h->d_split_stats, stt.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < LIO_MAX_ITERS; ++i) {
+            int64_t sc = 0, all = 0;
+            for (size_t g = 0; g < ng; ++g) {
+                sc += stt[(size_t)i * ng + g];
+                const LioScanState& st = h->h_state[h->v_groups[g].scan];
+                const int ran = st.status == 1 ? 0 : (st.status == 2 ? 1 : st.iter);
+                if (i < ran) all += h->v_groups[g].n;
+            }
+            h->prof.cert_points[i] = all;
+            h->prof.scan_points[i] = sc;
+        }
+    }
     return LIO_OK;
 }
 
