@@ -154,6 +154,25 @@ int  lio_s2m_batch_sync(lio_s2m_handle *h);
 int  lio_s2m_batch_results(lio_s2m_handle *h, float *poses /* n_scans x 6 */,
                            lio_s2m_result *results /* n_scans, may be NULL */);
 
+/* ---- streaming: upload batch k+1 while batch k iterates (SURVEY 8d puts the per-scan H2D inside the metric;
+ * the reference analogue is one cloud_info message arriving per callback, MO:432-476).
+ * lio_s2m_share_map: handle `h` searches `map_owner`'s resident map (no copy); it keeps its own HIP stream,
+ * scan buffers and per-scan state, so two handles form a double buffer:
+ *     run(A) ... upload_async(B, next batch) ... results(A) ... run(B) ... upload_async(A, ...) ...
+ * upload_async returns once the scans' H2D copies are DONE on h's stream (the caller's buffers are free
+ * again) while the tile sort is still in flight; set_poses/run/results queue behind it.  Copies are true DMA
+ * only from pinned memory: lio_host_alloc / lio_host_register (hipHostMalloc / hipHostRegister).  A batch laid
+ * out contiguously (scans[s+1] == scans[s] + n_pts[s]*stride) goes in one copy.  scans[] may also be DEVICE
+ * pointers (inputs already resident in HBM, e.g. the output of lio_deskew kept on the device).
+ * The owner must outlive the sharer; call lio_s2m_set_map on the owner only while both streams are idle. */
+int   lio_s2m_share_map(lio_s2m_handle *h, lio_s2m_handle *map_owner);
+int   lio_s2m_batch_upload_async(lio_s2m_handle *h, int32_t n_scans, const void *const *scans,
+                                 const size_t *n_pts, size_t stride_bytes);
+void *lio_host_alloc(size_t bytes);
+void  lio_host_free(void *p);
+int   lio_host_register(void *p, size_t bytes);
+int   lio_host_unregister(void *p);
+
 /* Persistent members MO:176-177 for batch slot `scan` (slot 0 = lio_s2m_register). */
 int  lio_s2m_set_degeneracy(lio_s2m_handle *h, int32_t scan, const float matP[36], int32_t is_degenerate);
 

@@ -111,6 +111,8 @@ EXPORTS = [
     "lio_s2m_set_corner_map", "lio_s2m_batch_upload_corners", "lio_s2m_register_cs",
     "lio_s2m_get_corner_correspondences", "lio_feature_default_config", "lio_extract_features",
     "lio_range_image_default_config", "lio_range_image",
+    "lio_s2m_share_map", "lio_s2m_batch_upload_async", "lio_host_alloc", "lio_host_free", "lio_host_register",
+    "lio_host_unregister",
 ]
 
 
@@ -135,6 +137,14 @@ def load_library():
     L.lio_s2m_set_map.argtypes = [vp, vp, sz, sz]
     L.lio_s2m_register.argtypes = [vp, vp, sz, sz, C.POINTER(f32), C.POINTER(S2MResult)]
     L.lio_s2m_batch_upload.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), sz]
+    L.lio_s2m_batch_upload_async.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), sz]
+    L.lio_s2m_share_map.argtypes = [vp, vp]
+    L.lio_host_alloc.argtypes = [sz]
+    L.lio_host_alloc.restype = vp
+    L.lio_host_free.argtypes = [vp]
+    L.lio_host_free.restype = None
+    L.lio_host_register.argtypes = [vp, sz]
+    L.lio_host_unregister.argtypes = [vp]
     L.lio_s2m_batch_set_poses.argtypes = [vp, C.POINTER(f32)]
     L.lio_s2m_batch_run.argtypes = [vp]
     L.lio_s2m_batch_sync.argtypes = [vp]
@@ -259,6 +269,21 @@ class ScanToMap:
         _check(self.lib.lio_s2m_batch_upload(self.h, n, ptrs, npts, strides.pop()), "lio_s2m_batch_upload")
         self._n_scans, self._npts = n, [len(a) for a, _ in arrs]
 
+    def share_map(self, owner):
+        """This handle searches `owner`'s resident map (double-buffered streaming, see include/liogpu.h)."""
+        _check(self.lib.lio_s2m_share_map(self.h, owner.h if owner is not None else None), "lio_s2m_share_map")
+        self._map_owner = owner          # keep it alive
+
+    def batch_upload_raw(self, base_ptr, n_pts, stride, asynchronous=True):
+        """Scans laid out back to back at `base_ptr` (pinned host or device memory): n_pts[s] records of `stride` bytes."""
+        n = len(n_pts)
+        offs = np.concatenate([[0], np.cumsum(np.asarray(n_pts, np.int64) * stride)])
+        ptrs = (C.c_void_p * n)(*[int(base_ptr) + int(o) for o in offs[:-1]])
+        npts = (C.c_size_t * n)(*[int(v) for v in n_pts])
+        fn = self.lib.lio_s2m_batch_upload_async if asynchronous else self.lib.lio_s2m_batch_upload
+        _check(fn(self.h, n, ptrs, npts, stride), "lio_s2m_batch_upload(_async)")
+        self._n_scans, self._npts = n, [int(v) for v in n_pts]
+
     def batch_set_poses(self, poses):
         p = np.ascontiguousarray(poses, np.float32).reshape(self._n_scans, 6)
         _check(self.lib.lio_s2m_batch_set_poses(self.h, _f32p(p)), "lio_s2m_batch_set_poses")
@@ -370,6 +395,30 @@ class ScanToMap:
         v = C.c_int32()
         _check(self.lib.lio_s2m_batch_n_active(self.h, C.byref(v)), "lio_s2m_batch_n_active")
         return v.value
+
+
+class PinnedBuffer:
+    """hipHostMalloc'ed bytes as a numpy array (true-DMA source for batch_upload_raw)."""
+
+    def __init__(self, nbytes):
+        self.lib = load_library()
+        self.nbytes = int(nbytes)
+        self.ptr = self.lib.lio_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise LioError("lio_host_alloc failed")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self.ptr))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.lib.lio_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # transformUpdate, MO:1867-1907

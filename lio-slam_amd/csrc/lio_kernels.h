@@ -63,10 +63,13 @@ void lio_launch_split_iteration(const LioSplitParams& S, int n_blocks, hipStream
 void lio_launch_pack_summary(const LioScanState* st, int n_scans, float* out, hipStream_t s);
 void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
                       int* n_active, hipStream_t s);
+void lio_launch_scan_bbox(const void* stage, size_t stride, const LioBlockDesc* prep_blocks, int n_prep_blocks,
+                          const LioScanState* st, unsigned* bbox, hipStream_t s);
 void lio_launch_scan_tile_sort(const void* stage, size_t stride, int total_pts,
                                const LioBlockDesc* prep_blocks, int n_prep_blocks,
                                const LioScanState* st, const LioScanTiles* tiles, int n_keys,
                                int* key_of, int* key_count, int* key_start, int* tile_sums,
-                               int* tmp_idx, int* perm, float* x, float* y, float* z, hipStream_t s);
+                               int* tmp_idx, int* perm, int* big_list, int* big_cnt,
+                               float* x, float* y, float* z, hipStream_t s);
 void lio_launch_exclusive_scan(const int* in, int n, int* tile_sums, int* out, hipStream_t s);
 void lio_launch_xyzi4_to_soa(const float4* src, int n, float* x, float* y, float* z, float4* xyz4, hipStream_t s);

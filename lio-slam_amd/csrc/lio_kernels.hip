@@ -284,6 +284,49 @@ LIO_DEV int lio_tile_coord(float v, float origin, float inv_tile, int n)
     return (int)c;
 }
 
+// Bounding box of every scan of the batch (finite coordinates only), one workgroup per 256 points:
+// bbox[scan][0..2] = min, [3..5] = max as order-preserving uints (initialised to ~0 / 0 by the host).
+__global__ __launch_bounds__(256) void k_scan_bbox(const unsigned char* __restrict__ stage, size_t stride,
+                                                   const LioBlockDesc* __restrict__ prep_blocks,
+                                                   const LioScanState* __restrict__ st, unsigned* __restrict__ bbox)
+{
+    const LioBlockDesc bd = prep_blocks[blockIdx.x];
+    const int li = bd.first + (int)threadIdx.x;
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    if (li < st[bd.scan].n_pts) {
+        const float* p = reinterpret_cast<const float*>(stage + (size_t)(st[bd.scan].offset + li) * stride);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = p[a];
+            if (fabsf(v) <= 3.0e38f) { mn[a] = v; mx[a] = v; }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    }
+    __shared__ float s_mn[4][3], s_mx[4][3];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float lo = s_mn[0][a], hi = s_mx[0][a];
+        for (int w = 1; w < 4; ++w) { lo = fminf(lo, s_mn[w][a]); hi = fmaxf(hi, s_mx[w][a]); }
+        if (lo <= hi) {
+            atomicMin(&bbox[bd.scan * 6 + a], lio_f2ord(lo));
+            atomicMax(&bbox[bd.scan * 6 + 3 + a], lio_f2ord(hi));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_scan_tile_keys(const unsigned char* __restrict__ stage, size_t stride,
                                                         const LioBlockDesc* __restrict__ prep_blocks,
                                                         const LioScanState* __restrict__ st,
@@ -313,10 +356,14 @@ __global__ void k_scan_tile_scatter(const int* __restrict__ key_of, int n, const
     tmp_idx[key_start[k] + atomicAdd(&key_fill[k], 1)] = i;
 }
 
-// one wave per tile: order the tile's points by their caller index (rank sort in LDS)
+// one wave per tile: order the tile's points by their caller index (rank sort in LDS).  Tiles with more
+// than LIO_TILE_CAP points (raw sweeps, very small leaf sizes) are copied as they are and queued for
+// k_scan_tile_bigsort, so that the order -- and with it every fp64 summation order -- never depends on the
+// arrival order of the atomics in k_scan_tile_scatter.
 #define LIO_TILE_CAP 1024
 __global__ __launch_bounds__(256) void k_scan_tile_ranksort(const int* __restrict__ key_start, int n_keys,
-                                                            const int* __restrict__ tmp_idx, int* __restrict__ perm)
+                                                            const int* __restrict__ tmp_idx, int* __restrict__ perm,
+                                                            int* __restrict__ big_list, int* __restrict__ big_cnt)
 {
     __shared__ int s_el[4][LIO_TILE_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -324,8 +371,9 @@ __global__ __launch_bounds__(256) void k_scan_tile_ranksort(const int* __restric
     if (k >= n_keys) return;
     const int b = key_start[k], n = key_start[k + 1] - b;
     if (n <= 0) return;
-    if (n > LIO_TILE_CAP) {                          // oversized tile: keep the scatter order
+    if (n > LIO_TILE_CAP) {                          // oversized tile: sorted by a whole workgroup afterwards
         for (int j = lane; j < n; j += 64) perm[b + j] = tmp_idx[b + j];
+        if (lane == 0) big_list[atomicAdd(big_cnt, 1)] = k;
         return;
     }
     for (int j = lane; j < n; j += 64) s_el[wave][j] = tmp_idx[b + j];
@@ -335,6 +383,39 @@ __global__ __launch_bounds__(256) void k_scan_tile_ranksort(const int* __restric
         int rank = 0;
         for (int i = 0; i < n; ++i) rank += (s_el[wave][i] < v) ? 1 : 0;
         perm[b + rank] = v;
+    }
+}
+
+// Oversized tiles: ascending sort of the tile's point indices in place (global memory, one workgroup per
+// tile, bitonic network in its all-ascending "flip" form so that the missing elements of the last
+// power-of-two block behave as +infinity).  The set of indices is fixed by the counting sort; only their
+// order came from atomics, and this removes it.
+__global__ __launch_bounds__(256) void k_scan_tile_bigsort(const int* __restrict__ key_start, const int* __restrict__ big_list,
+                                                           const int* __restrict__ big_cnt, int* __restrict__ perm)
+{
+    const int cnt = *big_cnt;
+    for (int t = blockIdx.x; t < cnt; t += gridDim.x) {
+        const int k = big_list[t];
+        const int b = key_start[k], n = key_start[k + 1] - b;
+        int* a = perm + b;
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        for (int size = 2; size <= np2; size <<= 1) {
+            const int half = size >> 1;
+            for (int i = threadIdx.x; i < (np2 >> 1); i += 256) {
+                const int blk = i / half, off = i - blk * half;
+                const int lo = blk * size + off, hi = blk * size + size - 1 - off;
+                if (hi < n) { const int x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
+            }
+            __syncthreads();
+            for (int st = half >> 1; st >= 1; st >>= 1) {
+                for (int i = threadIdx.x; i < (np2 >> 1); i += 256) {
+                    const int lo = (i / st) * 2 * st + (i % st), hi = lo + st;
+                    if (hi < n) { const int x = a[lo], y = a[hi]; if (x > y) { a[lo] = y; a[hi] = x; } }
+                }
+                __syncthreads();
+            }
+        }
     }
 }
 
@@ -842,14 +923,23 @@ void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const L
     hipLaunchKernelGGL(k_s2m_apply, dim3(n_scans), dim3(64), 0, s, st, n_scans, sums, c, n_active);
 }
 
+void lio_launch_scan_bbox(const void* stage, size_t stride, const LioBlockDesc* prep_blocks, int n_prep_blocks,
+                          const LioScanState* st, unsigned* bbox, hipStream_t s)
+{
+    if (n_prep_blocks <= 0) return;
+    hipLaunchKernelGGL(k_scan_bbox, dim3(n_prep_blocks), dim3(256), 0, s, (const unsigned char*)stage, stride, prep_blocks, st, bbox);
+}
+
 void lio_launch_scan_tile_sort(const void* stage, size_t stride, int total_pts,
                                const LioBlockDesc* prep_blocks, int n_prep_blocks,
                                const LioScanState* st, const LioScanTiles* tiles, int n_keys,
                                int* key_of, int* key_count, int* key_start, int* tile_sums,
-                               int* tmp_idx, int* perm, float* x, float* y, float* z, hipStream_t s)
+                               int* tmp_idx, int* perm, int* big_list, int* big_cnt,
+                               float* x, float* y, float* z, hipStream_t s)
 {
     if (total_pts <= 0 || n_prep_blocks <= 0) return;
     (void)hipMemsetAsync(key_count, 0, sizeof(int) * (size_t)n_keys, s);
+    (void)hipMemsetAsync(big_cnt, 0, sizeof(int), s);
     hipLaunchKernelGGL(k_scan_tile_keys, dim3(n_prep_blocks), dim3(256), 0, s,
                        (const unsigned char*)stage, stride, prep_blocks, st, tiles, key_of, key_count);
     const int n_tiles = (n_keys + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE;
@@ -859,7 +949,8 @@ void lio_launch_scan_tile_sort(const void* stage, size_t stride, int total_pts,
     (void)hipMemsetAsync(key_count, 0, sizeof(int) * (size_t)n_keys, s);
     const int nb = (total_pts + 255) / 256;
     hipLaunchKernelGGL(k_scan_tile_scatter, dim3(nb), dim3(256), 0, s, key_of, total_pts, key_start, key_count, tmp_idx);
-    hipLaunchKernelGGL(k_scan_tile_ranksort, dim3((n_keys + 3) / 4), dim3(256), 0, s, key_start, n_keys, tmp_idx, perm);
+    hipLaunchKernelGGL(k_scan_tile_ranksort, dim3((n_keys + 3) / 4), dim3(256), 0, s, key_start, n_keys, tmp_idx, perm, big_list, big_cnt);
+    hipLaunchKernelGGL(k_scan_tile_bigsort, dim3(64), dim3(256), 0, s, key_start, big_list, big_cnt, perm);
     hipLaunchKernelGGL(k_scan_gather_sorted, dim3(nb), dim3(256), 0, s, (const unsigned char*)stage, stride,
                        total_pts, perm, x, y, z);
 }

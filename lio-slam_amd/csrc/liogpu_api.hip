@@ -97,7 +97,12 @@ struct lio_s2m_handle {
     int* d_key_tiles = nullptr; size_t cap_key_tiles = 0;
     int* d_tmp_idx = nullptr; size_t cap_tmp_idx = 0;
     int* d_perm = nullptr; size_t cap_perm = 0;
+    int* d_big_list = nullptr; size_t cap_big_list = 0;   // tiles with more than LIO_TILE_CAP points (+ their count in the last slot)
+    unsigned* d_scan_bbox = nullptr; size_t cap_scan_bbox = 0;   // [n_scans][6] ordered-uint bounding boxes
+    unsigned* h_scan_bbox = nullptr; size_t cap_h_scan_bbox = 0; // pinned mirror
     bool sorted = false;
+    lio_s2m_handle* map_src = nullptr;   // lio_s2m_share_map: the handle whose resident map this one searches
+    unsigned long long map_epoch = 0;    // bumped by every set_map
     float* d_nn_cache = nullptr; size_t cap_nn_cache = 0;   // [total_pts] squared 5th-neighbour distance of the previous GN iteration
     long long* d_stamps = nullptr; size_t cap_stamps = 0;
     // split pipeline (cfg.pipeline): neighbour cache + per-iteration scan work list
@@ -254,7 +259,7 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
                      h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
                      h->d_nn_cache, h->d_summary, h->d_groups, h->d_cache_idx, h->d_cache_q, h->d_pt_flag,
-                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats };
+                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < LIO_MAX_ITERS; ++i) {               // (a handle whose creation failed half-way holds nulls)
         if (h->ev_beg[i]) (void)hipEventDestroy(h->ev_beg[i]);
@@ -263,6 +268,7 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
     }
     if (h->h_active) (void)hipHostFree(h->h_active);
     if (h->h_summary) (void)hipHostFree(h->h_summary);
+    if (h->h_scan_bbox) (void)hipHostFree(h->h_scan_bbox);
     if (h->ev_map[0]) (void)hipEventDestroy(h->ev_map[0]);
     if (h->ev_map[1]) (void)hipEventDestroy(h->ev_map[1]);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
@@ -290,6 +296,8 @@ static float lio_ord2f(unsigned u)
     memcpy(&f, &v, 4);
     return f;
 }
+
+static const lio_s2m_handle* lio_map_of(const lio_s2m_handle* h) { return h->map_src ? h->map_src : h; }
 
 // ------------------------------------------------------------------ set_map
 static int lio_map_reserve(lio_s2m_handle* h, size_t n)
@@ -368,6 +376,7 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
     h->has_map = true;
     h->graph_dirty = true;
     h->cache_dirty = true;            // cached neighbour indices refer to the previous map
+    h->map_epoch++;
     return LIO_OK;
 }
 
@@ -377,6 +386,7 @@ extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, siz
     if (n > 0 && !pts) return lio_fail(LIO_ERR_ARG, "null map pointer");
     if (stride < 12 || (stride & 3)) return lio_fail(LIO_ERR_ARG, "stride_bytes must be >= 12 and a multiple of 4");
     if (n >= (1ull << 25)) return lio_fail(LIO_ERR_CAPACITY, "map too large ((2k+1)^2 x n records must fit a 31-bit offset)");
+    if (h->map_src) return lio_fail(LIO_ERR_ARG, "this handle searches another handle's map (lio_s2m_share_map)");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     auto t0 = std::chrono::steady_clock::now();
@@ -421,6 +431,52 @@ extern "C" int lio_s2m_set_scan_shard(lio_s2m_handle* h, int32_t rank, int32_t w
     h->block_rank = rank;
     h->block_world = world;
     return LIO_OK;
+}
+
+// Streaming (the metric includes the per-scan H2D): a second handle searches THIS handle's resident
+// map, with its own stream and its own scan buffers, so that batch k+1 can be uploaded and tile-sorted while
+// batch k iterates.  The map owner must outlive the sharer; replacing the map needs both streams idle.
+extern "C" int lio_s2m_share_map(lio_s2m_handle* h, lio_s2m_handle* map_owner)
+{
+    if (!h || h == map_owner) return lio_fail(LIO_ERR_ARG, "need two different handles");
+    if (map_owner && (map_owner->map_src || map_owner->cfg.device_id != h->cfg.device_id))
+        return lio_fail(LIO_ERR_ARG, "the map owner must hold its own map on the same device");
+    h->map_src = map_owner;
+    h->map_epoch = map_owner ? map_owner->map_epoch : 0;
+    h->cache_dirty = true;
+    h->graph_dirty = true;
+    return LIO_OK;
+}
+
+extern "C" void* lio_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void lio_host_free(void* p) { if (p) (void)hipHostFree(p); }
+extern "C" int lio_host_register(void* p, size_t bytes)
+{
+    if (!p || !bytes) return lio_fail(LIO_ERR_ARG, "null range");
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return LIO_OK;
+}
+extern "C" int lio_host_unregister(void* p)
+{
+    if (!p) return lio_fail(LIO_ERR_ARG, "null pointer");
+    HIPCHK(hipHostUnregister(p));
+    return LIO_OK;
+}
+
+extern "C" int lio_s2m_batch_upload_async(lio_s2m_handle* h, int32_t n_scans, const void* const* scans,
+                                          const size_t* n_pts, size_t stride)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    const bool keep = h->defer_sync;
+    h->defer_sync = true;
+    const int rc = lio_s2m_batch_upload(h, n_scans, scans, n_pts, stride);
+    h->defer_sync = keep;
+    return rc;
 }
 
 extern "C" int lio_s2m_set_shard(lio_s2m_handle* h, int32_t axis, int32_t lo, int32_t hi)
@@ -545,10 +601,25 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         const int nb_local = b1 - b0;
         if (nb_local > max_blk) max_blk = nb_local;
         for (int b = b0; b < b1; ++b) blocks.push_back({ s, (int)(b * per_blk), b - b0, nb_local });
-        if (n_pts[s])
-            HIPCHK(hipMemcpyAsync(h->d_stage + off * stride, scans[s], n_pts[s] * stride,
-                                  hipMemcpyHostToDevice, h->stream));
         off += n_pts[s];
+    }
+    // H2D (or D2D: device pointers are accepted, hipMemcpyDefault) of the caller's records as they are.  A batch
+    // that is one contiguous block in the caller's memory -- what a streaming front end keeps in a pinned ring --
+    // goes in ONE copy; pageable or scattered scans are copied one by one.
+    {
+        bool contiguous = true;
+        for (int s = 0; s + 1 < n_scans && contiguous; ++s)
+            contiguous = (const unsigned char*)scans[s + 1] == (const unsigned char*)scans[s] + n_pts[s] * stride;
+        if (contiguous && total) {
+            HIPCHK(hipMemcpyAsync(h->d_stage, scans[0], total * stride, hipMemcpyDefault, h->stream));
+        } else {
+            size_t o = 0;
+            for (int s = 0; s < n_scans; ++s) {
+                if (n_pts[s])
+                    HIPCHK(hipMemcpyAsync(h->d_stage + o * stride, scans[s], n_pts[s] * stride, hipMemcpyDefault, h->stream));
+                o += n_pts[s];
+            }
+        }
     }
     h->v_first_orig.assign((size_t)n_scans + 1, 0);
     for (const LioBlockDesc& b : blocks) h->v_first_orig[b.scan + 1]++;
@@ -583,18 +654,37 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     h->sorted = false;
     // the tile sort pays for itself on batches; a lone small scan skips its eight launches
     if (total && (h->cfg.sort_scan == 2 || (h->cfg.sort_scan == 1 && total >= 65536))) {
-        // scan-local tile grids from the host-side bounding boxes
+        // scan-local tile grids from the scans' bounding boxes, reduced on the device (the caller's memory is
+        // never read by the host: it may be pinned, pageable or device memory)
+        for (int s = 0; s < n_scans; ++s) {
+            const int nb1 = (int)((n_pts[s] + LIO_BLOCK - 1) / LIO_BLOCK);
+            for (int b = 0; b < nb1; ++b) prep.push_back({ s, b * LIO_BLOCK, b, nb1 });
+        }
+        HIPCHK(lio_grow(&h->d_prep_blocks, &h->cap_prep_blocks, prep.size()));
+        HIPCHK(lio_grow(&h->d_scan_bbox, &h->cap_scan_bbox, (size_t)n_scans * 6));
+        if (h->cap_h_scan_bbox < (size_t)n_scans * 6) {
+            if (h->h_scan_bbox) HIPCHK(hipHostFree(h->h_scan_bbox));
+            h->h_scan_bbox = nullptr; h->cap_h_scan_bbox = 0;
+            HIPCHK(hipHostMalloc((void**)&h->h_scan_bbox, ((size_t)n_scans * 6 + 64) * sizeof(unsigned), hipHostMallocDefault));
+            h->cap_h_scan_bbox = (size_t)n_scans * 6 + 64;
+        }
+        for (int s = 0; s < n_scans; ++s)
+            for (int a = 0; a < 6; ++a) h->h_scan_bbox[s * 6 + a] = a < 3 ? 0xffffffffu : 0u;
+        HIPCHK(hipMemcpyAsync(h->d_scan_bbox, h->h_scan_bbox, (size_t)n_scans * 6 * sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_prep_blocks, prep.data(), prep.size() * sizeof(LioBlockDesc), hipMemcpyHostToDevice, h->stream));
+        lio_launch_scan_bbox(h->d_stage, stride, h->d_prep_blocks, (int)prep.size(), h->d_state, h->d_scan_bbox, h->stream);
+        HIPCHK(hipMemcpyAsync(h->h_scan_bbox, h->d_scan_bbox, (size_t)n_scans * 6 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));          // (this handle's stream only: a sibling handle keeps computing)
         tiles.resize((size_t)n_scans);
         long long n_keys = 0;
         for (int s = 0; s < n_scans; ++s) {
-            float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
-            const unsigned char* src = (const unsigned char*)scans[s];
-            for (size_t i = 0; i < n_pts[s]; ++i) {
-                const float* p = (const float*)(src + i * stride);
-                for (int a = 0; a < 3; ++a)
-                    if (fabsf(p[a]) <= 3.0e38f) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
+            float mn[3], mx[3];
+            for (int a = 0; a < 3; ++a) {
+                const unsigned lo = h->h_scan_bbox[s * 6 + a], hi = h->h_scan_bbox[s * 6 + 3 + a];
+                const bool none = lo == 0xffffffffu;
+                mn[a] = none ? 0.0f : lio_ord2f(lo);
+                mx[a] = none ? 0.0f : lio_ord2f(hi);
             }
-            for (int a = 0; a < 3; ++a) if (!(mn[a] <= mx[a])) { mn[a] = 0.0f; mx[a] = 0.0f; }
             float tile = h->cfg.tile_size > 0.0f ? h->cfg.tile_size : 4.0f;
             LioScanTiles t;
             for (;;) {
@@ -608,23 +698,21 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
             t.key_offset = (int)n_keys;
             tiles[s] = t;
             n_keys += (long long)t.ntx * t.nty * t.ntz;
-            const int nb1 = (int)((n_pts[s] + LIO_BLOCK - 1) / LIO_BLOCK);
-            for (int b = 0; b < nb1; ++b) prep.push_back({ s, b * LIO_BLOCK, b, nb1 });
         }
         if (n_keys < 0x7fffffffLL - 1024) {
             HIPCHK(lio_grow(&h->d_tiles, &h->cap_tiles, (size_t)n_scans));
-            HIPCHK(lio_grow(&h->d_prep_blocks, &h->cap_prep_blocks, prep.size()));
             HIPCHK(lio_grow(&h->d_key_of, &h->cap_key_of, tt));
+            HIPCHK(lio_grow(&h->d_big_list, &h->cap_big_list, tt / 1024 + 2));
             HIPCHK(lio_grow(&h->d_tmp_idx, &h->cap_tmp_idx, tt));
             HIPCHK(lio_grow(&h->d_perm, &h->cap_perm, tt));
             HIPCHK(lio_grow(&h->d_key_count, &h->cap_key_count, (size_t)n_keys));
             HIPCHK(lio_grow(&h->d_key_start, &h->cap_key_start, (size_t)n_keys + 1));
             HIPCHK(lio_grow(&h->d_key_tiles, &h->cap_key_tiles, (size_t)lio_scan_tiles((int)n_keys) + 1));
             HIPCHK(hipMemcpyAsync(h->d_tiles, tiles.data(), tiles.size() * sizeof(LioScanTiles), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(h->d_prep_blocks, prep.data(), prep.size() * sizeof(LioBlockDesc), hipMemcpyHostToDevice, h->stream));
             lio_launch_scan_tile_sort(h->d_stage, stride, (int)total, h->d_prep_blocks, (int)prep.size(), h->d_state,
                                       h->d_tiles, (int)n_keys, h->d_key_of, h->d_key_count, h->d_key_start,
-                                      h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_sx, h->d_sy, h->d_sz, h->stream);
+                                      h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_big_list, h->d_big_list + (h->cap_big_list - 1),
+                                      h->d_sx, h->d_sy, h->d_sz, h->stream);
             h->sorted = true;
         }
     }
@@ -732,7 +820,8 @@ extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
         // Locality only: order the workgroup list by where the scans ARE (position along the map's
         // longest axis).  Together with the XCD-aware workgroup order every XCD then streams the
         // map rows of one stretch of the trajectory, which fit its private 4 MB L2.
-        const float ext[3] = { (float)h->grid.nx, (float)h->grid.ny, (float)h->grid.nz };
+        const LioGrid& mg = lio_map_of(h)->grid;
+        const float ext[3] = { (float)mg.nx, (float)mg.ny, (float)mg.nz };
         const int ax = (ext[0] >= ext[1] && ext[0] >= ext[2]) ? 0 : (ext[1] >= ext[2] ? 1 : 2);
         std::vector<int>& order = h->v_order;
         order.resize((size_t)h->n_scans);
@@ -779,14 +868,15 @@ extern "C" int lio_s2m_set_degeneracy(lio_s2m_handle* h, int32_t scan, const flo
 
 static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_out)
 {
-    P.grid = h->grid;
+    const lio_s2m_handle* m = lio_map_of(h);       // (a sibling's resident map after lio_s2m_share_map)
+    P.grid = m->grid;
     P.shard = h->shard;
     P.c = h->c;
-    P.map_sorted = h->d_sorted;
-    P.map_xyz4 = h->d_map4;
-    P.cell_start = h->d_cell_start;
-    P.nbr_pts = h->d_nbr_pts;
-    P.nbr_start = h->d_nbr_start;
+    P.map_sorted = m->d_sorted;
+    P.map_xyz4 = m->d_map4;
+    P.cell_start = m->d_cell_start;
+    P.nbr_pts = m->d_nbr_pts;
+    P.nbr_start = m->d_nbr_start;
     P.sx = h->d_sx; P.sy = h->d_sy; P.sz = h->d_sz;
     P.perm = h->sorted ? h->d_perm : nullptr;
     P.state = h->d_state;
@@ -854,8 +944,13 @@ static void lio_launch_gn(lio_s2m_handle* h, const LioIterParams& P, const LioIt
 extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
 {
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
-    if (!h->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
+    if (!lio_map_of(h)->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
     if (h->n_scans < 1 || !h->poses_set) return lio_fail(LIO_ERR_ARG, "batch_upload and batch_set_poses first");
+    if (h->map_src && h->map_epoch != h->map_src->map_epoch) {      // the shared map was replaced since the last run
+        h->map_epoch = h->map_src->map_epoch;
+        h->cache_dirty = true;
+        h->graph_dirty = true;
+    }
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->c, h->d_active, h->stream);
@@ -1129,7 +1224,7 @@ extern "C" int lio_s2m_register(lio_s2m_handle* h, const void* scan, size_t n, s
                                 float pose[6], lio_s2m_result* res)
 {
     if (!h || !pose) return lio_fail(LIO_ERR_ARG, "null argument");
-    if (!h->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
+    if (!lio_map_of(h)->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
     const void* scans[1] = { scan };
     size_t np[1] = { n };
     // upload, poses and the GN loop are chained on the stream; the only host wait is for the results

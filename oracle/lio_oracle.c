@@ -769,6 +769,11 @@ int lo_lm_optimization(const lo_s2m_config *cfg, int iter_count,
 
 /* ----------------------------------------------------- scan2MapOptimization */
 
+/* wall time of the last kd-tree build in lo_scan2map (the reference rebuilds its tree for every scan, MO:1846):
+ * lets the CPU baseline report the build / query split */
+static double lo_last_build_s = 0.0;
+double lo_last_kdtree_build_seconds(void) { return lo_last_build_s; }
+
 int lo_scan2map(const lo_s2m_config *cfg,
                 const float *scan_xyz, size_t n_scan,
                 const float *map_xyz, size_t n_map,
@@ -779,12 +784,18 @@ int lo_scan2map(const lo_s2m_config *cfg,
     memset(res, 0, sizeof(*res));
     res->is_degenerate = *is_degenerate_io;
     memcpy(res->matP, matP_io, sizeof(float) * 36);
+    if (cfg->max_iters < 1 || cfg->max_iters > 32) {                    /* the per-iteration trace holds 32 entries: refuse, never clamp */
+        res->status = -1;
+        return res->status;
+    }
     if (!((long)n_scan > (long)cfg->min_scan_pts)) {                    /* MO:1844 */
         res->status = LO_TOO_FEW_POINTS;
         return res->status;
     }
     lo_kdtree *tree = NULL;
+    const double t_build0 = omp_get_wtime();
     if (cfg->knn_mode == 1) tree = lo_kdtree_build(map_xyz, n_map);     /* MO:1846 */
+    lo_last_build_s = omp_get_wtime() - t_build0;
 
     uint8_t *flag = (uint8_t *)malloc(n_scan);
     float *coeff = (float *)malloc(sizeof(float) * 4 * n_scan);
@@ -792,7 +803,7 @@ int lo_scan2map(const lo_s2m_config *cfg,
     float *ori_sel = (float *)malloc(sizeof(float) * 3 * n_scan);
     float *coeff_sel = (float *)malloc(sizeof(float) * 4 * n_scan);
 
-    int max_iters = cfg->max_iters > 32 ? 32 : cfg->max_iters;
+    const int max_iters = cfg->max_iters;
     for (int it = 0; it < max_iters; ++it) {                            /* MO:1848 */
         lo_surf_optimization(cfg, pose, scan_xyz, n_scan, map_xyz, n_map, tree, flag, coeff, nn);
         if (it == corr_iter) {
@@ -1562,6 +1573,7 @@ int lo_scan2map_cs(const lo_s2m_config *cfg,
     memset(res, 0, sizeof(*res));
     res->is_degenerate = *is_degenerate_io;
     memcpy(res->matP, matP_io, sizeof(float) * 36);
+    if (cfg->max_iters < 1 || cfg->max_iters > 32) { res->status = -1; return res->status; }
     if (!((long)n_surf > (long)cfg->min_scan_pts)) { res->status = LO_TOO_FEW_POINTS; return res->status; }
     lo_kdtree *stree = cfg->knn_mode == 1 ? lo_kdtree_build(smap_xyz, n_smap) : NULL;
     lo_kdtree *ctree = (cfg->knn_mode == 1 && n_corner) ? lo_kdtree_build(cmap_xyz, n_cmap) : NULL;
@@ -1571,7 +1583,7 @@ int lo_scan2map_cs(const lo_s2m_config *cfg,
     int32_t *nn = (int32_t *)malloc(sizeof(int32_t) * 5 * (n_all ? n_all : 1));
     float *ori_sel = (float *)malloc(sizeof(float) * 3 * (n_all ? n_all : 1));
     float *coeff_sel = (float *)malloc(sizeof(float) * 4 * (n_all ? n_all : 1));
-    int max_iters = cfg->max_iters > 32 ? 32 : cfg->max_iters;
+    const int max_iters = cfg->max_iters;
     for (int it = 0; it < max_iters; ++it) {
         if (n_corner) lo_corner_optimization(cfg, pose, corner_xyz, n_corner, cmap_xyz, n_cmap, ctree, flag, coeff, nn);
         lo_surf_optimization(cfg, pose, surf_xyz, n_surf, smap_xyz, n_smap, stree,

@@ -141,6 +141,9 @@ int lo_scan2map(const lo_s2m_config *cfg,
                 lo_s2m_result *res,
                 int corr_iter, uint8_t *corr_flag, float *corr_coeff, int32_t *corr_nn);
 
+/* wall time (s) of the kd-tree build of the last lo_scan2map call in this process (MO:1846) */
+double lo_last_kdtree_build_seconds(void);
+
 /* transformUpdate + constraintTransformation, MO:1867-1907 */
 void lo_transform_update(float pose[6], int imu_available, int imu_type,
                          float imu_roll_init, float imu_pitch_init, float imu_rpy_weight,

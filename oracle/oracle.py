@@ -91,6 +91,8 @@ class Oracle:
         L.lo_scan2map.argtypes = [C.POINTER(S2MConfig), _f32p, C.c_size_t, _f32p, C.c_size_t,
                                   _f32p, _f32p, _i32p, C.POINTER(S2MResult),
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lo_last_kdtree_build_seconds.restype = C.c_double
+        L.lo_last_kdtree_build_seconds.argtypes = []
         L.lo_transform_update.argtypes = [_f32p, C.c_int, C.c_int] + [C.c_float] * 5
         L.lo_imu_deskew_info.restype = C.c_int
         L.lo_imu_deskew_info.argtypes = [_f64p, _f64p, _f64p, _f64p, C.c_int, C.c_double, C.c_double,
@@ -119,6 +121,10 @@ class Oracle:
         L.lo_scan2map_cs.argtypes = [C.POINTER(S2MConfig), _f32p, C.c_size_t, _f32p, C.c_size_t, _f32p, C.c_size_t,
                                      _f32p, C.c_size_t, _f32p, _f32p, _i32p, C.POINTER(S2MResult),
                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def last_kdtree_build_seconds(self):
+        """Wall time of the kd-tree build inside the last scan2map() call (MO:1846)."""
+        return float(self.lib.lo_last_kdtree_build_seconds())
 
     # ---- helpers -----------------------------------------------------------
     def default_config(self, **kw):

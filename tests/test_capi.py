@@ -97,3 +97,20 @@ def test_host_side_scalar_code_matches_oracle(pkg, oracle):
     assert a[0] == b[0] > 10
     for x, y in zip(a[1:], b[1:]):
         np.testing.assert_array_equal(x, y)
+
+
+def test_out_of_range_config_is_refused_not_clamped(pkg, oracle):
+    """k != 5 (MO:1631 hard-codes 5) and max_iters beyond the 32-entry iteration trace return LIO_ERR_ARG from
+    lio_s2m_create -- before any device is touched -- and the oracle refuses the same configuration."""
+    lib = pkg.load_library()
+    for field, bad in (("k", 4), ("k", 6), ("max_iters", 0), ("max_iters", 33), ("max_sq_dist", 0.0)):
+        cfg = pkg.S2MConfig()
+        lib.lio_s2m_default_config(C.byref(cfg))
+        setattr(cfg, field, bad)
+        h = C.c_void_p()
+        assert lib.lio_s2m_create(C.byref(cfg), C.byref(h)) == -1, (field, bad)      # LIO_ERR_ARG
+        assert not h.value
+    ocfg = oracle.default_config(max_iters=33)
+    scan = np.zeros((100, 3), np.float32)
+    _, res, _, _ = oracle.scan2map(ocfg, scan, scan, np.zeros(6, np.float32))
+    assert res.status == -1
