@@ -1,21 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- scan-to-map registrations/sec on MI355X (BASELINE.json metric).
 
-Workload (config.workload): 64x1800-point synthetic scans registered against a
-200-keyframe local map resident in HBM.  One "step" = one batch of B scans,
-each with its own initial guess, run through the whole Gauss-Newton loop
-(<= 30 iterations, every scan stops at its own convergence, MO:1848-1859).
-Scans, map and hash grid are resident before the timed region; each step
-uploads only the B initial poses and reads back the B results.
+Workload (config.workload): 64x1800-point synthetic scans registered against a 200-keyframe local map
+resident in HBM.  One "step" = one batch of B scans taken through the WHOLE device-side path of the
+boundary: the raw pcl::PointXYZI records of the batch (resident in HBM when the timed region starts) are
+staged, tile-sorted into the SoA layout, every scan gets its own initial guess and runs the Gauss-Newton
+loop (<= 30 iterations, each scan stops at its own convergence, MO:1848-1859), and the B results are read
+back.  Every step registers a DIFFERENT batch (`--batches` distinct batches are cycled); two handles
+sharing the resident map form a double buffer, so the staging + sort of batch k+1 overlaps the GN loop of
+batch k.  Also reported, never as `value`: the same stream with the records coming from pinned HOST memory
+over PCIe (`streamed_h2d`), the GN loop alone on a pre-sorted resident batch (`gn_loop_only`, round 1's
+definition), and the single-scan sequence a patched node issues per callback (`single_scan_node_path_ms`).
 
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: the MAP is sharded across ranks in slabs of grid cells with a one-cell
-halo (north_star / SURVEY 8e); every rank processes the scan points whose
-transformed position falls into a cell it owns and the per-scan 6x6 JtJ / 6x1
-Jtr / N_c are all-reduced (RCCL over xGMI) once per Gauss-Newton iteration.
-The batch grows with N (B = batch x N scans) => weak scaling.
+N > 1 (north_star / SURVEY 8e): the MAP is sharded across ranks in slabs of grid cells with a one-cell halo;
+every rank processes the scan points whose transformed position falls into a cell it owns and the per-scan
+6x6 JtJ / 6x1 Jtr / N_c are all-reduced (RCCL over xGMI) once per Gauss-Newton iteration.  The batch grows
+with N (B = batch x N scans per step) => weak scaling.
 """
 import argparse
 import importlib
@@ -32,6 +35,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_POINT_ITER = 72  # 12 B scan xyz + 5 x 12 B winning neighbours
+PARITY_BASIS = ("CPU restatement of the reference source (oracle/lio_oracle.c); Eigen / OpenCV / FLANN / PCL arithmetic "
+                "restated from their published algorithms; unpinned by any reference-held fixture (the reference has none "
+                "and cannot be built here)")
 
 
 def rot_angle(pa, pb, synth):
@@ -60,9 +66,20 @@ def host_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(scans, map_xyz, poses0, budget_s, log):
-    """CPU restatement of the reference loop (oracle, own kd-tree incl. the per-scan
-    tree build MO:1846, OpenMP over scan points MO:1622) on a bounded sample."""
+    """CPU restatement of the reference loop (oracle: own kd-tree rebuilt per scan as MO:1846 does, OpenMP over
+    scan points as MO:1622) on a bounded sample of the batch, at the reference's own thread counts
+    (numberOfCores: 4 in lio_sam_default.yaml:63, 12 in 6t.yaml:119) and at all cores of the box."""
     from oracle.oracle import Oracle, build
     import tempfile
     cores = host_cores()
@@ -74,38 +91,62 @@ def cpu_baseline(scans, map_xyz, poses0, budget_s, log):
         so = os.path.join(ROOT, "oracle", "liblio_oracle.so")
         kind_flags = "-O2"
     orc = Oracle(so)
-    cfg = orc.default_config(knn_mode=1, n_threads=cores)
-    done, t_used, poses, iters = 0, 0.0, [], []
-    # the batch's scans in order, wrapping around until the time budget is used (poses are kept for the first pass)
-    while done < 8 * len(scans) and (done < 2 or t_used < budget_s):
-        i = done % len(scans)
-        t0 = time.perf_counter()
-        p, res, _, _ = orc.scan2map(cfg, scans[i], map_xyz, poses0[i])
-        t_used += time.perf_counter() - t0
-        if done < len(scans):
-            poses.append(p)
-            iters.append(res.iters)
-        done += 1
+    by_threads, poses, iters = {}, [], []
+    counts = sorted({min(4, cores), min(12, cores), cores})
+    for nt in counts:
+        cfg = orc.default_config(knn_mode=1, n_threads=nt)
+        done, t_used, t_build = 0, 0.0, 0.0
+        budget = budget_s * (0.5 if nt == cores else 0.5 / max(len(counts) - 1, 1))
+        # the batch's scans in order, wrapping around until the time budget is used
+        while done < 8 * len(scans) and (done < 2 or t_used < budget):
+            i = done % len(scans)
+            t0 = time.perf_counter()
+            p, res, _, _ = orc.scan2map(cfg, scans[i], map_xyz, poses0[i])
+            t_used += time.perf_counter() - t0
+            t_build += orc.last_kdtree_build_seconds()
+            if nt == cores and done < len(scans):
+                poses.append(p)
+                iters.append(res.iters)
+            done += 1
+        by_threads[str(nt)] = {"registrations_per_s": done / t_used, "ms_per_registration": 1e3 * t_used / done,
+                               "ms_kdtree_build": 1e3 * t_build / done, "ms_gn_loop": 1e3 * (t_used - t_build) / done,
+                               "registrations": done, "seconds": t_used}
+        log(f"cpu_baseline {nt} threads: {done / t_used:.1f} reg/s ({done} registrations, kd-tree build {1e3 * t_build / done:.2f} ms each)")
+    top = by_threads[str(cores)]
     return {
-        "value": done / t_used, "unit": "registrations/s", "cores": cores, "kind": "port",
-        "sample": f"{done} registrations over the batch's {len(scans)} scans, {t_used:.1f} s; oracle/lio_oracle.c ({kind_flags}, "
-                  f"-ffp-contract=off), own kd-tree rebuilt per scan, OpenMP {cores} threads",
-        "ms_per_registration": 1e3 * t_used / done,
+        "value": top["registrations_per_s"], "unit": "registrations/s", "cores": cores, "kind": "port",
+        "sample": f"{top['registrations']} registrations over the first scans of the workload, {top['seconds']:.1f} s; "
+                  f"oracle/lio_oracle.c ({kind_flags}, -ffp-contract=off), own kd-tree rebuilt per scan (MO:1846, "
+                  f"{top['ms_kdtree_build']:.2f} ms of the {top['ms_per_registration']:.2f} ms), OpenMP {cores} threads on a {cpu_model()}",
+        "ms_per_registration": top["ms_per_registration"], "by_threads": by_threads, "cpu_model": cpu_model(),
+        "label": "CPU restatement of the reference algorithm (own kd-tree), not the reference binary",
     }, np.array(poses), iters
+
+
+def to_records(scans, stride):
+    """Back-to-back records of `stride` bytes, x,y,z at byte 0,4,8 (stride 32 = pcl::PointXYZI, UT:65)."""
+    n = sum(len(s) for s in scans)
+    rec = np.zeros((n, stride // 4), np.float32)
+    rec[:, :3] = np.concatenate(scans)
+    if stride >= 32:
+        rec[:, 3] = 1.0
+    return rec
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100, help="timed steps (one step = the whole GN loop for the batch, ~2 ms: the default keeps the timed window at ~0.2 s so that one host hiccup cannot dominate it)")
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=64, help="timed steps (one step = one batch through staging, tile sort, the whole GN loop and the result read-back)")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=512, help="scans per GPU per step")
+    ap.add_argument("--batches", type=int, default=0, help="distinct batches cycled through (0 = 8 on one GPU, 2 on several)")
+    ap.add_argument("--stride", type=int, default=32, help="bytes per input record (32 = pcl::PointXYZI, 16 = xyzi floats, 12 = packed xyz)")
     ap.add_argument("--sensor", default="hdl64")
     ap.add_argument("--keyframes", type=int, default=200)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (streamed H2D, GN loop only, node path, feeders)")
     ap.add_argument("--variant", type=int, default=1, help="scan points per thread (1, 2, 4)")
-    ap.add_argument("--latency", action="store_true", help="also time single-scan registrations")
     ap.add_argument("--case-cache", default="", help="npz path: load the synthetic case if present, else generate and save")
     ap.add_argument("--lds", type=int, default=0)
     ap.add_argument("--sort", type=int, default=1)
@@ -115,12 +156,13 @@ def main():
     ap.add_argument("--tile", type=float, default=0.0)
     ap.add_argument("--lookahead", type=int, default=0)
     ap.add_argument("--graph", type=int, default=12, help="replay a hipGraph of this many GN iterations per launch unit (0 = eager launches)")
-    ap.add_argument("--shard", choices=["map", "scan"], default="scan",
+    ap.add_argument("--shard", choices=["map", "scan"], default="map",
                     help="N>1: map = slabs of the map + halo, owner-computes (north_star); scan = map replicated, workgroups of every scan dealt round-robin")
     ap.add_argument("--nncache", type=int, default=1, help="1 = bound each point's search by its previous neighbours (exact)")
+    ap.add_argument("--pipeline", type=int, default=0, help="0/1 = fused k_s2m_iterate, 2 = split cert/scan/fit (A/B only)")
+    ap.add_argument("--single-buffer", action="store_true", help="A/B: one handle, no overlap of staging and GN loop")
     ap.add_argument("--maxsq", type=float, default=1.0, help="DIAGNOSTIC: squared 5-NN gate (reference: 1.0); smaller values shrink the "
                     "searched neighbourhood and change the results -- only for timing what-if runs")
-    ap.add_argument("--pipeline", type=int, default=0, help="0 = auto, 1 = fused k_s2m_iterate, 2 = split cert/scan/fit")
     ap.add_argument("--lawnmower", action="store_true", help="keyframes on a lawn-mower path inside a 50 m radius (configs[3])")
     args = ap.parse_args()
 
@@ -168,19 +210,25 @@ def main():
     multi = importlib.import_module("lio-slam_amd.multigpu") if sharded else None
 
     # ---------------------------------------------------------------- data
-    B = args.batch * world
+    B = args.batch * world                       # scans per step, job-wide
+    NB = args.batches if args.batches > 0 else (8 if not sharded else 2)
+    NQ = B * NB
     t0 = time.time()
     keyframes = []          # (cloud in lidar frame, pose) of every map keyframe, when generated here
 
     def generate():
         if args.case_cache and os.path.exists(args.case_cache):
             z = np.load(args.case_cache)
-            offs = np.concatenate([[0], np.cumsum(z["lens"])])
-            sc = [np.ascontiguousarray(z["scans"][offs[i]:offs[i + 1]]) for i in range(len(z["lens"]))]
-            assert len(sc) == B, "case cache was generated for another batch size"
-            return z["map"], sc, z["poses0"], z["poses_true"]
-        case = synth.make_case(args.sensor, n_keyframes=args.keyframes, seed=synth.BASE_SEED, n_queries=B,
-                               device=f"cuda:{local_rank}", lawnmower=args.lawnmower,
+            lens = z["lens"]
+            if len(lens) == NQ:
+                offs = np.concatenate([[0], np.cumsum(lens)])
+                cat = z["scans"]                     # (an NpzFile re-reads the member on every access: take it ONCE)
+                sc = [np.ascontiguousarray(cat[offs[i]:offs[i + 1]]) for i in range(NQ)]
+                del cat
+                return z["map"], sc, z["poses0"], z["poses_true"]
+            log("case cache was generated for another workload size: regenerating")
+        case = synth.make_case(args.sensor, n_keyframes=args.keyframes, seed=synth.BASE_SEED, n_queries=NQ,
+                               device=f"cuda:{local_rank}", lawnmower=args.lawnmower, workers=min(8, host_cores()),
                                progress=lambda k, n: log(f"map keyframe {k}/{n}"))
         keyframes.extend(case["keyframes"])
         sc = [q["scan"] for q in case["queries"]]
@@ -202,71 +250,46 @@ def main():
             dist.broadcast(t, src)
             return t.cpu().numpy()
 
-        per = args.batch
-        if args.case_cache and os.path.exists(args.case_cache):
-            if rank == 0:
-                map_xyz, scans_all, poses0, poses_true = generate()
-            share = None
-        else:
-            case = synth.make_case(args.sensor, n_keyframes=args.keyframes, seed=synth.BASE_SEED, n_queries=B,
-                                   device=f"cuda:{local_rank}", lawnmower=args.lawnmower, q_range=(rank * per, (rank + 1) * per),
-                                   with_map=(rank == 0), progress=lambda k, n: log(f"map keyframe {k}/{n}"))
-            if rank == 0:
-                map_xyz = case["map"]
-                keyframes.extend(case["keyframes"])
-            share = [q for q in case["queries"] if q is not None]
+        per = NQ // world
+        case = synth.make_case(args.sensor, n_keyframes=args.keyframes, seed=synth.BASE_SEED, n_queries=NQ,
+                               device=f"cuda:{local_rank}", lawnmower=args.lawnmower, q_range=(rank * per, (rank + 1) * per),
+                               with_map=(rank == 0), workers=min(8, max(1, host_cores() // max(world, 1))),
+                               progress=lambda k, n: log(f"map keyframe {k}/{n}"))
+        if rank == 0:
+            map_xyz = case["map"]
+            keyframes.extend(case["keyframes"])
+        share = [q for q in case["queries"] if q is not None]
         hdr = torch.tensor([len(map_xyz) if rank == 0 else 0], dtype=torch.int64, device="cuda")
         dist.broadcast(hdr, 0)
         map_xyz = bcast(map_xyz if rank == 0 else None, (int(hdr[0]), 3), torch.float32)
-        if share is None:                                    # case cache: rank 0 holds everything
-            lens = bcast(np.array([len(x) for x in scans_all], np.int64) if rank == 0 else None, (B,), torch.int64)
-            cat = bcast(np.concatenate(scans_all) if rank == 0 else None, (int(lens.sum()), 3), torch.float32)
-            poses0 = bcast(poses0 if rank == 0 else None, (B, 6), torch.float32)
-            poses_true = bcast(poses_true if rank == 0 else None, (B, 6), torch.float32)
-        else:
-            lens_l, cats, p0s, pts = [], [], [], []
-            for r in range(world):                           # one broadcast round per rank's share
-                mine = rank == r
-                ln = bcast(np.array([len(q["scan"]) for q in share], np.int64) if mine else None, (per,), torch.int64, src=r)
-                cats.append(bcast(np.concatenate([q["scan"] for q in share]) if mine else None, (int(ln.sum()), 3), torch.float32, src=r))
-                p0s.append(bcast(np.stack([q["pose_init"] for q in share]).astype(np.float32) if mine else None, (per, 6), torch.float32, src=r))
-                pts.append(bcast(np.stack([q["pose_true"] for q in share]).astype(np.float32) if mine else None, (per, 6), torch.float32, src=r))
-                lens_l.append(ln)
-            lens, cat = np.concatenate(lens_l), np.concatenate(cats)
-            poses0, poses_true = np.concatenate(p0s), np.concatenate(pts)
+        lens_l, cats, p0s, pts = [], [], [], []
+        for r in range(world):                           # one broadcast round per rank's share
+            mine = rank == r
+            ln = bcast(np.array([len(q["scan"]) for q in share], np.int64) if mine else None, (per,), torch.int64, src=r)
+            cats.append(bcast(np.concatenate([q["scan"] for q in share]) if mine else None, (int(ln.sum()), 3), torch.float32, src=r))
+            p0s.append(bcast(np.stack([q["pose_init"] for q in share]).astype(np.float32) if mine else None, (per, 6), torch.float32, src=r))
+            pts.append(bcast(np.stack([q["pose_true"] for q in share]).astype(np.float32) if mine else None, (per, 6), torch.float32, src=r))
+            lens_l.append(ln)
+        lens, cat = np.concatenate(lens_l), np.concatenate(cats)
+        poses0, poses_true = np.concatenate(p0s), np.concatenate(pts)
         offs = np.concatenate([[0], np.cumsum(lens)])
-        scans = [np.ascontiguousarray(cat[offs[i]:offs[i + 1]]) for i in range(B)]
+        scans = [np.ascontiguousarray(cat[offs[i]:offs[i + 1]]) for i in range(NQ)]
     n_s = np.array([len(s) for s in scans])
     log(f"data: N_m={len(map_xyz)} N_s mean={n_s.mean():.0f} min={n_s.min()} max={n_s.max()} "
-        f"B={B} gen {time.time() - t0:.1f}s")
+        f"{NB} batches x {B} scans, gen {time.time() - t0:.1f}s")
+
+    # raw records of every batch, resident in HBM (what the boundary is handed: pcl::PointXYZI AoS)
+    stride = args.stride
+    batch_scans = [scans[b * B:(b + 1) * B] for b in range(NB)]
+    batch_npts = [[len(s) for s in bs] for bs in batch_scans]
+    batch_rec = [to_records(bs, stride) for bs in batch_scans]
+    dev_rec = [torch.from_numpy(r).cuda() for r in batch_rec]
+    torch.cuda.synchronize()
 
     # -------------------------------------------------------------- engine
     kcfg = dict(device_id=local_rank, profile=1, use_graph=1 if args.graph else 0, graph_iters=max(args.graph, 1), lookahead=args.lookahead, kernel_variant=args.variant,
-                use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch, nn_cache=args.nncache, max_sq_dist=args.maxsq, pipeline=args.pipeline)
-    if sharded:
-        # the host runs `lookahead` GN iterations ahead of the convergence check (never 0 here: polling the
-        # iteration just enqueued would drain the GPU once per iteration and sub-batch)
-        kcfg_sh = dict(kcfg)
-        kcfg_sh.pop("lookahead")
-        runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2,
-                                     lookahead=max(args.lookahead, int(os.environ.get("BENCH_SHARD_LAG", "2"))), **kcfg_sh)
-        runner.upload(scans)
-        s2m = runner.handles[0]
-    else:
-        runner = None
-        s2m = pkg.ScanToMap(**kcfg)
-        s2m.set_map(map_xyz)
-        s2m.batch_upload(scans)
-    prof0 = s2m.profile()
-
-    def step():
-        if runner:
-            runner.set_poses(poses0)
-            runner.run()
-            return runner.results(with_results=False)[0]
-        s2m.batch_set_poses(poses0)
-        s2m.batch_run()
-        return s2m.batch_results(with_results=False)[0]
+                use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch, nn_cache=args.nncache,
+                max_sq_dist=args.maxsq, pipeline=args.pipeline)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -274,53 +297,81 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if sharded:
+        # the host runs `lookahead` GN iterations ahead of the convergence check (never 0 here: polling the
+        # iteration just enqueued would drain the GPU once per iteration and sub-batch)
+        kcfg_sh = dict(kcfg)
+        kcfg_sh.pop("lookahead")
+        runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2,
+                                     lookahead=max(args.lookahead, int(os.environ.get("BENCH_SHARD_LAG", "2"))), **kcfg_sh)
+        handles = [runner.handles[0]]
+        prof0 = handles[0].profile()
+
+        def run_stream(n_steps, sources, first_batch=0, keep=None):
+            """One step = stage + tile-sort batch k (every rank holds every scan: ownership follows the pose), GN loop
+            with one all-reduce per iteration, results."""
+            out = None
+            for k in range(n_steps):
+                b = (first_batch + k) % NB
+                runner.upload_raw(sources[b].data_ptr(), batch_npts[b], stride)
+                runner.set_poses(poses0[b * B:(b + 1) * B])
+                runner.run()
+                out = runner.results(with_results=False)[0]
+                if keep is not None and b == 0:
+                    keep["poses"] = out
+            return out
+    else:
+        runner = None
+        hA = pkg.ScanToMap(**kcfg)
+        hA.set_map(map_xyz)
+        prof0 = hA.profile()
+        handles = [hA]
+        if not args.single_buffer:
+            hB = pkg.ScanToMap(**kcfg)
+            hB.share_map(hA)
+            handles.append(hB)
+
+        def run_stream(n_steps, sources, first_batch=0, keep=None):
+            """Software pipeline over the handles: GN loop of batch k (asynchronous) || staging + tile sort of batch
+            k+1 on the other handle's stream, then the results of batch k."""
+            nh = len(handles)
+            ptr = lambda b: sources[b].data_ptr() if hasattr(sources[b], "data_ptr") else sources[b].ptr
+            handles[0].batch_upload_raw(ptr(first_batch % NB), batch_npts[first_batch % NB], stride)
+            out = None
+            for k in range(n_steps):
+                b = (first_batch + k) % NB
+                h = handles[k % nh]
+                h.batch_set_poses(poses0[b * B:(b + 1) * B])
+                h.batch_run()
+                if nh > 1 and k + 1 < n_steps:
+                    nb_ = (b + 1) % NB
+                    handles[(k + 1) % nh].batch_upload_raw(ptr(nb_), batch_npts[nb_], stride)
+                out = h.batch_results(with_results=False)[0]
+                if nh == 1 and k + 1 < n_steps:
+                    nb_ = (b + 1) % NB
+                    h.batch_upload_raw(ptr(nb_), batch_npts[nb_], stride)
+                if keep is not None and b == 0:
+                    keep["poses"] = out
+            return out
+
+    keep = {}
+    run_stream(args.warmup, dev_rec, keep=keep)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        poses = step()
+    run_stream(args.steps, dev_rec, first_batch=args.warmup, keep=keep)
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    value = B * args.steps / elapsed
+    last_b = (args.warmup + args.steps - 1) % NB          # the batch of the last timed step
 
-    # N > 1 only: the same registrations with NO collective -- every rank registers its own share of the batch
-    # against the replicated map through the single-GPU path (hipGraph loop).  Registrations are independent
-    # objects, so this is the natural partition of the batch (BASELINE.json configs[4]); it is reported next to
-    # `value`, which stays the north_star's form (one registration's work spread over the ranks, all-reduce per
-    # GN iteration).
-    replica = None
-    if runner and world > 1:
-        per = args.batch
-        mine = slice(rank * per, (rank + 1) * per)
-        rep = pkg.ScanToMap(**kcfg)
-        rep.set_map(map_xyz)
-        rep.batch_upload(scans[mine])
-
-        def rep_step():
-            rep.batch_set_poses(poses0[mine])
-            rep.batch_run()
-            return rep.batch_results(with_results=False)[0]
-
-        for _ in range(args.warmup):
-            rep_step()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            rep_poses = rep_step()
-        sync_all()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        replica = {"value": B * args.steps / float(t.item()), "unit": "registrations/s",
-                   "note": "whole scans dealt to the ranks, map replicated, no collective (independent registrations)"}
-        rep.close()
-
-    # per-launch accounting from the last timed step
+    # per-launch accounting of the dominant kernel from the LAST timed step (HIP events on the handle's stream)
+    ns_last = n_s[last_b * B:(last_b + 1) * B]
     if runner:
-        poses, results = runner.results(with_results=True)
+        poses_last, results = runner.results(with_results=True)
         iters = np.array([r.iters for r in results])
         lms, pts_per_launch = [], []
         for (a, b_), hh in zip(runner.split, runner.handles):      # every sub-batch has its own launches
@@ -328,12 +379,13 @@ def main():
             for i in range(pr.n_launches):
                 lms.append(pr.launch_ms[i])
                 # this rank handles 1/world of the points of the scans still iterating
-                pts_per_launch.append(float(n_s[a:b_][iters[a:b_] > i].sum()) / world)
+                pts_per_launch.append(float(ns_last[a:b_][iters[a:b_] > i].sum()) / world)
         lms, pts_per_launch = np.array(lms, dtype=np.float64), np.array(pts_per_launch, dtype=np.float64)
-        n_launch = len(lms)
+        prof = None
     else:
-        poses, results = s2m.batch_results(with_results=True)
-        prof = s2m.profile()
+        h_last = handles[(args.steps - 1) % len(handles)]
+        poses_last, results = h_last.batch_results(with_results=True)
+        prof = h_last.profile()
         iters = np.array([r.iters for r in results])
         # a unit = one launch (eager) or one replay of a captured chunk of unit_iters launches; the
         # average launch duration and the average algorithmic bytes are both taken over ALL launches
@@ -342,86 +394,197 @@ def main():
         n_launch = prof.n_units * ui
         unit_ms = np.array(prof.launch_ms[:prof.n_units], dtype=np.float64)
         lms = np.repeat(unit_ms / ui, ui)
-        pts_per_launch = np.array([int(n_s[iters > i].sum()) for i in range(n_launch)], dtype=np.float64)
+        pts_per_launch = np.array([int(ns_last[iters > i].sum()) for i in range(n_launch)], dtype=np.float64)
     live = lms > 0
     bytes_per_launch = BYTES_PER_POINT_ITER * pts_per_launch[live].mean() if live.any() else 0.0
     ms_per_launch = float(lms[live].mean()) if live.any() else float("nan")
     achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if live.any() else 0.0
 
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if os.path.exists(tpath) and not sharded:
         tj = json.load(open(tpath))
         if (tj.get("scans_per_step"), tj.get("N_m")) == (B, int(len(map_xyz))):
-            traffic = tj["hbm_bytes_per_launch"]      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, see DESIGN.md
+            traffic = tj["hbm_bytes_per_launch"]      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, see DESIGN.md
 
-    value = B * args.steps / elapsed
     out = {
         "metric": "scan-to-map registrations/sec, 64x1800 scan vs 200-keyframe map; pose RMSE",
         "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "parity_basis": PARITY_BASIS,
         "config": {
             "workload": f"{args.sensor} {synth.SENSORS[args.sensor][0]}x{synth.SENSORS[args.sensor][1]} synthetic street-canyon "
                         f"scans vs {args.keyframes}-keyframe map (BASELINE.json headline = hdl64 64x1800 vs 200; "
-                        f"configs[4] batched form)",
-            "scans_per_step": B, "N_s_mean": float(n_s.mean()), "N_m": int(len(map_xyz)),
+                        f"configs[4] batched form), {NB} distinct batches streamed",
+            "timed_region": "per step, for a batch not seen in the previous step: staging of the raw records (resident in HBM) + AoS->SoA + "
+                            "tile sort, B initial poses in, whole GN loop, B results out" + ("" if sharded else
+                            "; double-buffered over two handles sharing the map" if len(handles) > 1 else "; single handle"),
+            "inputs_resident_in_hbm": True, "h2d_in_timed_region": False, "input_record_bytes": stride,
+            "scans_per_step": B, "distinct_batches": NB, "N_s_mean": float(n_s.mean()), "N_m": int(len(map_xyz)),
             "gn_iters_mean": float(iters.mean()), "gn_iters_max": int(iters.max()),
             "parallelism": "single GPU" if not sharded else
             (f"map sharded x{world} (slabs + halo, owner-computes)" if args.shard == "map" else
              f"map replicated, scan workgroups dealt over {world} ranks") + " + RCCL all-reduce of JtJ/Jtr per GN iteration",
-            "kernel": {"points_per_thread": int(args.variant), "lds_staging": int(args.lds),
+            "kernel": {"points_per_thread": int(args.variant), "lds_staging": int(args.lds), "pipeline": "split" if args.pipeline == 2 else "fused",
                        "nn_cache": args.nncache, "tile_sorted_scans": int(args.sort), "cell_div": int(args.celldiv)},
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "k_s2m_iterate", "ms_per_launch": ms_per_launch,
-            "limiter": "not HBM: the per-lane candidate stream is bound by divergent 16-byte load instructions through the "
-                       "texture addresser (~77 % busy) with VALU issue at ~60 %; see DESIGN.md section 6",
+            "kernel": "k_s2m_iterate" if args.pipeline != 2 else "k_s2m_cert + k_s2m_scan + k_s2m_fit (one GN iteration)",
+            "ms_per_launch": ms_per_launch,
+            "limiter": "not HBM: VALU issue (about 2100 vector instructions per 64 live points and iteration, of which the candidate "
+                       "scan is ~40 % and the bit-exact plane fit ~40 %) with the divergent candidate gathers keeping the texture "
+                       "addresser ~75 % busy; see DESIGN.md section 6",
             "launches_per_step": int(live.sum()), "launches_per_graph_replay": int(args.graph), "algorithmic_bytes_per_launch": bytes_per_launch,
             "launch_ms": [round(float(v), 4) for v in lms], "launch_points": [int(v) for v in pts_per_launch],
+            "measured": "HIP events around the graph replays of the last timed step on the handle's own stream, while the other "
+                        "handle's staging/sort kernels run concurrently",
         },
-        "gn_pipeline": None if runner else {"kind": "split (k_s2m_cert + k_s2m_scan + k_s2m_fit per iteration)" if prof.pipeline == 2 else "fused (k_s2m_iterate)",
-                                            "points_per_iteration": [int(v) for v in prof.cert_points[:n_launch]],
-                                            "points_scanned_per_iteration": [int(v) for v in prof.scan_points[:n_launch]]},
         "map_build_ms": prof0.map_build_ms, "map_upload_ms": prof0.map_upload_ms,
         "grid_cells": int(prof0.n_cells),
     }
+    if prof is not None and prof.pipeline == 2:
+        out["gn_pipeline"] = {"points_per_iteration": [int(v) for v in prof.cert_points[:n_launch]],
+                              "points_scanned_per_iteration": [int(v) for v in prof.scan_points[:n_launch]]}
+
+    extras = not args.no_extras
+    # -------------------------------------------------- secondary measurements (never `value`)
+    if extras and not sharded:
+        # (1) the same stream with the records in pinned HOST memory: per-scan H2D over PCIe inside the timed region
+        pins = []
+        for r in batch_rec:
+            p = pkg.PinnedBuffer(r.nbytes)
+            p.array[:] = r.view(np.uint8).reshape(-1)
+            pins.append(p)
+        n_st = max(8, args.steps // 2)
+        run_stream(4, pins)
+        sync_all()
+        t0 = time.perf_counter()
+        run_stream(n_st, pins, first_batch=4)
+        sync_all()
+        el = time.perf_counter() - t0
+        out["streamed_h2d"] = {"value": B * n_st / el, "unit": "registrations/s", "ms_per_step": 1e3 * el / n_st, "steps": n_st,
+                               "h2d_in_timed_region": True, "h2d_bytes_per_step": int(batch_rec[0].nbytes),
+                               "pcie_gbs_sustained": batch_rec[0].nbytes * n_st / el / 1e9,
+                               "note": "the metric as SURVEY 8(d) words it: scans arrive from (pinned) host memory as "
+                                       f"{stride}-byte records; upload of batch k+1 overlaps the GN loop of batch k"}
+        for p in pins:
+            p.close()
+        # (2) round 1's definition: GN loop only, one pre-sorted resident batch re-registered from its initial poses
+        g = handles[0]
+        g.batch_upload(batch_scans[0])
+
+        def gn_step():
+            g.batch_set_poses(poses0[:B])
+            g.batch_run()
+            return g.batch_results(with_results=False)[0]
+
+        for _ in range(3):
+            gn_step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(32):
+            gn_step()
+        sync_all()
+        el = time.perf_counter() - t0
+        out["gn_loop_only"] = {"value": B * 32 / el, "unit": "registrations/s", "ms_per_step": 1e3 * el / 32,
+                               "note": "inputs uploaded and tile-sorted once outside the timer (round 1's `value`)"}
+
+    # N > 1 only: the same registrations with NO collective -- every rank registers its own share of the batch
+    # against the replicated map through the single-GPU path.  Registrations are independent objects, so this is
+    # the natural partition of the batch (BASELINE.json configs[4]); it is reported next to `value`, which stays
+    # the north_star's form (one registration's work spread over the ranks, all-reduce per GN iteration).
+    if runner and world > 1 and extras:
+        per = args.batch
+        rep = pkg.ScanToMap(**kcfg)
+        rep.set_map(map_xyz)
+        rep2 = pkg.ScanToMap(**kcfg)
+        rep2.share_map(rep)
+        hs = [rep, rep2]
+        my = [[scans[b * B + rank * per + i] for i in range(per)] for b in range(NB)]
+        my_rec = [torch.from_numpy(to_records(m, stride)).cuda() for m in my]
+        my_n = [[len(s) for s in m] for m in my]
+        my_p0 = [poses0[b * B + rank * per: b * B + (rank + 1) * per] for b in range(NB)]
+
+        def rep_stream(n_steps):
+            hs[0].batch_upload_raw(my_rec[0].data_ptr(), my_n[0], stride)
+            for k in range(n_steps):
+                b = k % NB
+                h = hs[k % 2]
+                h.batch_set_poses(my_p0[b]); h.batch_run()
+                if k + 1 < n_steps:
+                    hs[(k + 1) % 2].batch_upload_raw(my_rec[(b + 1) % NB].data_ptr(), my_n[(b + 1) % NB], stride)
+                h.batch_results(with_results=False)
+
+        rep_stream(args.warmup)
+        sync_all()
+        t0 = time.perf_counter()
+        rep_stream(args.steps)
+        sync_all()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["batch_sharded_no_collective"] = {"value": B * args.steps / float(t.item()), "unit": "registrations/s",
+                                              "note": "whole scans dealt to the ranks, map replicated, no collective (independent registrations), same timed region"}
+        rep2.close(); rep.close()
 
     if rank == 0:
-        if replica:
-            out["batch_sharded_no_collective"] = replica
-        rt, rr = rmse_pair(poses, poses_true, synth)
-        out["pose_rmse_vs_truth"] = {"trans_m": rt, "rot_rad": rr}
+        gpu0 = keep.get("poses")
+        if gpu0 is not None:
+            rt, rr = rmse_pair(gpu0, poses_true[:B], synth)
+            out["pose_rmse_vs_truth"] = {"trans_m": rt, "rot_rad": rr, "scans": B}
         if not args.no_cpu and world == 1:      # the CPU baseline is timed at N = 1 only (the other ranks would idle)
-            cb, cpu_poses, cpu_iters = cpu_baseline(scans, map_xyz, poses0, args.cpu_seconds, log)
+            cb, cpu_poses, cpu_iters = cpu_baseline(scans[:B], map_xyz, poses0[:B], args.cpu_seconds, log)
             out["cpu_baseline"] = cb
             k = len(cpu_poses)
-            rt, rr = rmse_pair(poses[:k], cpu_poses, synth)
-            out["pose_rmse_vs_cpu"] = {"trans_m": rt, "rot_rad": rr, "scans": k,
-                                       "bit_identical": int(sum(np.array_equal(a, b) for a, b in zip(poses[:k], cpu_poses))),
-                                       "iters_equal": bool(list(iters[:k]) == list(cpu_iters))}
-        if keyframes and not sharded:
-            # feeder: extractCloud MO:1556-1588 on the GPU, host clouds in, map resident out
+            if gpu0 is not None and k:
+                rt, rr = rmse_pair(gpu0[:k], cpu_poses, synth)
+                out["pose_rmse_vs_cpu"] = {"trans_m": rt, "rot_rad": rr, "scans": k,
+                                           "bit_identical": int(sum(np.array_equal(a, b) for a, b in zip(gpu0[:k], cpu_poses))),
+                                           "basis": "parity with the CPU restatement, see parity_basis"}
+        if keyframes and not sharded and extras:
+            # the sequence INTEGRATION.md wires into the node, per callback (MO:1846-1861): local map from the resident
+            # keyframes (extractCloud MO:1556-1588) or set_map from the host, ONE registration incl. H2D of the scan and
+            # D2H of the result, transformUpdate
             kc = [np.concatenate([c, np.zeros((len(c), 1), np.float32)], 1) for c, _ in keyframes]
             kp = np.stack([p for _, p in keyframes])
-            asm = pkg.ScanToMap(device_id=local_rank)
+            node = pkg.ScanToMap(device_id=local_rank)
             store = pkg.KeyframeStore(device_id=local_rank)
             t0 = time.perf_counter()
             ids = [store.add(c) for c in kc]                       # once per keyframe, MO:2138-2142
             t_add = time.perf_counter() - t0
-            store.assemble(ids, kp, 0.5, s2m=asm, want_output=False)
-            t0 = time.perf_counter()
-            reps = 5
-            for _ in range(reps):                                  # once per scan, MO:1556-1588 + MO:1846
-                _, n_asm, _ = store.assemble(ids, kp, 0.5, s2m=asm, want_output=False)
-            out["map_assembly"] = {"ms_per_scan_resident_keyframes_incl_grid_build": 1e3 * (time.perf_counter() - t0) / reps,
-                                   "ms_keyframe_upload_total": 1e3 * t_add,
-                                   "keyframes": len(kc), "points_in": int(sum(len(c) for c in kc)), "points_out": int(n_asm)}
+            n_lat = 32
+            pcl_scans = [to_records([scans[i]], 32) for i in range(n_lat)]
+            store.assemble(ids, kp, 0.5, s2m=node, want_output=False)
+            for i in range(3):
+                node.scan2MapOptimization(pcl_scans[i], poses0[i])
+            t_asm = t_reg = t_upd = 0.0
+            for i in range(n_lat):
+                t0 = time.perf_counter()
+                _, n_asm, _ = store.assemble(ids, kp, 0.5, s2m=node, want_output=False)
+                t1 = time.perf_counter()
+                p, _, _ = node.scan2MapOptimization(pcl_scans[i], poses0[i])
+                t2 = time.perf_counter()
+                pkg.transform_update(p)
+                t3 = time.perf_counter()
+                t_asm += t1 - t0; t_reg += t2 - t1; t_upd += t3 - t2
+            map_rec = to_records([map_xyz], 32)
+            t_set = 0.0
+            for i in range(8):
+                t0 = time.perf_counter()
+                node.set_map(map_rec)
+                t_set += time.perf_counter() - t0
+            out["single_scan_node_path_ms"] = {
+                "assemble_map_resident_keyframes": 1e3 * t_asm / n_lat, "register_incl_h2d_d2h": 1e3 * t_reg / n_lat,
+                "transform_update": 1e3 * t_upd / n_lat, "total_resident_keyframes": 1e3 * (t_asm + t_reg + t_upd) / n_lat,
+                "set_map_from_host_instead": 1e3 * t_set / 8, "total_set_map_from_host": 1e3 * (t_set / 8 + (t_reg + t_upd) / n_lat),
+                "registrations_per_s_single_stream": n_lat / (t_asm + t_reg + t_upd),
+                "scans": n_lat, "note": "one scan per callback as the reference issues it (MO:432-476, MO:1846-1861); Python ctypes caller"}
+            out["map_assembly"] = {"ms_keyframe_upload_total": 1e3 * t_add, "keyframes": len(kc),
+                                   "points_in": int(sum(len(c) for c in kc)), "points_out": int(n_asm)}
             store.close()
-            asm.close()
-        if keyframes and not sharded:
+            node.close()
             # the step after the deskew: FeatureExtraction::laserCloudInfoHandler FE:67-77 for one
             # organised 64x1800 sweep, host arrays in, corner/surface clouds out
             boxes = synth.make_scene(synth.BASE_SEED, length=max(60.0, float(args.keyframes) + 20.0))
@@ -434,22 +597,12 @@ def main():
             out["feature_extraction"] = {"ms_per_sweep_incl_h2d_d2h": 1e3 * (time.perf_counter() - t0) / 5,
                                          "points": int(len(org["cloud"])), "corner": int(len(fe["corner"])),
                                          "surface": int(len(fe["surface"]))}
-        if args.latency and not sharded:
-            lat = pkg.ScanToMap(device_id=local_rank)
-            lat.set_map(map_xyz)
-            for i in range(3):
-                lat.scan2MapOptimization(scans[i % B], poses0[i % B])
-            t0 = time.perf_counter()
-            n_lat = min(B, 32)
-            for i in range(n_lat):
-                lat.scan2MapOptimization(scans[i], poses0[i])
-            out["single_scan_ms_incl_h2d"] = 1e3 * (time.perf_counter() - t0) / n_lat
-            lat.close()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if runner:
         runner.close()
     else:
-        s2m.close()
+        for h in reversed(handles):
+            h.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -130,6 +130,11 @@ struct lio_s2m_handle {
     float* d_rec_coeff = nullptr; size_t cap_rec_coeff = 0;
     int* d_rec_nn = nullptr; size_t cap_rec_nn = 0;
 
+    // resumable launch loop (lio_s2m_batch_run / lio_run_continue)
+    bool run_pending = false, run_graph = false, run_has_c = false;
+    int run_next = 0, run_units = 0, run_look = 0;
+    LioIterParams run_P, run_Pc;
+
     // sharding
     LioShard shard{};
     float gorigin[3] = {0, 0, 0};
@@ -541,6 +546,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         if (n_pts[s] > max_n) max_n = n_pts[s];
     }
     if (total > 0x7fffffffull - 1024) return lio_fail(LIO_ERR_CAPACITY, "batch too large");
+    h->run_pending = false;            // (a run whose results were never fetched is abandoned)
     if (h->host_state_stale && h->n_scans > 0 && h->d_state) {
         // the persistent members (matP / isDegenerate, MO:176-177) live in the device copy: bring the host copy
         // up to date before it is edited and uploaded again
@@ -603,14 +609,25 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         for (int b = b0; b < b1; ++b) blocks.push_back({ s, (int)(b * per_blk), b - b0, nb_local });
         off += n_pts[s];
     }
-    // H2D (or D2D: device pointers are accepted, hipMemcpyDefault) of the caller's records as they are.  A batch
-    // that is one contiguous block in the caller's memory -- what a streaming front end keeps in a pinned ring --
-    // goes in ONE copy; pageable or scattered scans are copied one by one.
+    // The caller's records as they are.  A batch that is one contiguous block in the caller's memory -- what a
+    // streaming front end keeps in a pinned ring -- goes to the device in ONE copy; pageable or scattered scans are
+    // copied one by one; a contiguous batch that already lives in THIS device's memory is not copied at all: the
+    // sort kernels read it in place (it must stay valid until the next lio_s2m_batch_sync / _results).
+    const unsigned char* stage = h->d_stage;
     {
         bool contiguous = true;
         for (int s = 0; s + 1 < n_scans && contiguous; ++s)
             contiguous = (const unsigned char*)scans[s + 1] == (const unsigned char*)scans[s] + n_pts[s] * stride;
+        bool in_place = false;
         if (contiguous && total) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, scans[0]) == hipSuccess)
+                in_place = at.type == hipMemoryTypeDevice && at.device == h->cfg.device_id;
+            (void)hipGetLastError();                     // (pageable host memory is reported as an error)
+        }
+        if (in_place) {
+            stage = (const unsigned char*)scans[0];
+        } else if (contiguous && total) {
             HIPCHK(hipMemcpyAsync(h->d_stage, scans[0], total * stride, hipMemcpyDefault, h->stream));
         } else {
             size_t o = 0;
@@ -672,7 +689,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
             for (int a = 0; a < 6; ++a) h->h_scan_bbox[s * 6 + a] = a < 3 ? 0xffffffffu : 0u;
         HIPCHK(hipMemcpyAsync(h->d_scan_bbox, h->h_scan_bbox, (size_t)n_scans * 6 * sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_prep_blocks, prep.data(), prep.size() * sizeof(LioBlockDesc), hipMemcpyHostToDevice, h->stream));
-        lio_launch_scan_bbox(h->d_stage, stride, h->d_prep_blocks, (int)prep.size(), h->d_state, h->d_scan_bbox, h->stream);
+        lio_launch_scan_bbox(stage, stride, h->d_prep_blocks, (int)prep.size(), h->d_state, h->d_scan_bbox, h->stream);
         HIPCHK(hipMemcpyAsync(h->h_scan_bbox, h->d_scan_bbox, (size_t)n_scans * 6 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));          // (this handle's stream only: a sibling handle keeps computing)
         tiles.resize((size_t)n_scans);
@@ -709,7 +726,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
             HIPCHK(lio_grow(&h->d_key_start, &h->cap_key_start, (size_t)n_keys + 1));
             HIPCHK(lio_grow(&h->d_key_tiles, &h->cap_key_tiles, (size_t)lio_scan_tiles((int)n_keys) + 1));
             HIPCHK(hipMemcpyAsync(h->d_tiles, tiles.data(), tiles.size() * sizeof(LioScanTiles), hipMemcpyHostToDevice, h->stream));
-            lio_launch_scan_tile_sort(h->d_stage, stride, (int)total, h->d_prep_blocks, (int)prep.size(), h->d_state,
+            lio_launch_scan_tile_sort(stage, stride, (int)total, h->d_prep_blocks, (int)prep.size(), h->d_state,
                                       h->d_tiles, (int)n_keys, h->d_key_of, h->d_key_count, h->d_key_start,
                                       h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_big_list, h->d_big_list + (h->cap_big_list - 1),
                                       h->d_sx, h->d_sy, h->d_sz, h->stream);
@@ -717,7 +734,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         }
     }
     if (total && !h->sorted)
-        lio_launch_aos_to_soa(h->d_stage, stride, (int)total, h->d_sx, h->d_sy, h->d_sz, nullptr, h->stream);
+        lio_launch_aos_to_soa(stage, stride, (int)total, h->d_sx, h->d_sy, h->d_sz, nullptr, h->stream);
     HIPCHK(hipMemsetAsync(h->d_arrive, 0, (size_t)n_scans * sizeof(unsigned), h->stream));
     if (!h->defer_sync) HIPCHK(hipStreamSynchronize(h->stream));   // the caller's scans are borrowed only for this call
     HIPCHK(hipGetLastError());
@@ -815,6 +832,7 @@ extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
     if (h->n_scans < 1) return lio_fail(LIO_ERR_ARG, "no batch uploaded");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
+    h->run_pending = false;            // (a run whose results were never fetched is abandoned)
     HIPCHK(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_scans * 6 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     if (h->cfg.sort_batch && h->n_scans > 8 && !h->v_blocks.empty()) {
         // Locality only: order the workgroup list by where the scans ARE (position along the map's
@@ -1000,22 +1018,55 @@ static int lio_graph_prepare(lio_s2m_handle* h, const LioIterParams& P, const Li
     return LIO_OK;
 }
 
+// The GN loop (MO:1848-1859) as a resumable launch loop.  After every launch unit (one launch, or one replay of a
+// captured chunk of `graph_iters` launches) the count of still-iterating scans is copied to pinned memory; unit u
+// is only enqueued once the count after unit u-1-lookahead is known to be non-zero (lookahead 0 never enqueues an
+// empty launch; larger values keep the queue fed for small batches).  `blocking == false` (lio_s2m_batch_run)
+// enqueues what can be enqueued WITHOUT waiting for the device and returns -- the caller is free to upload the
+// next batch on a sibling handle --; lio_s2m_batch_sync / _results resume the loop with `blocking == true`.
+static int lio_run_continue(lio_s2m_handle* h, bool blocking)
+{
+    if (!h->run_pending) return LIO_OK;
+    const bool prof = h->cfg.profile != 0;
+    const LioIterParams* Pc = h->run_has_c ? &h->run_Pc : nullptr;
+    while (h->run_next < h->run_units && h->run_next < LIO_MAX_ITERS) {          // MO:1848
+        const int u = h->run_next;
+        const int chk = u - 1 - h->run_look;
+        if (chk >= 0) {
+            if (blocking) {
+                HIPCHK(hipEventSynchronize(h->ev_chk[chk]));
+            } else {
+                const hipError_t q = hipEventQuery(h->ev_chk[chk]);
+                if (q == hipErrorNotReady) { (void)hipGetLastError(); return LIO_OK; }   // resumed by sync / results
+                HIPCHK(q);
+            }
+            if (h->h_active[chk] == 0) break;
+        }
+        if (prof) HIPCHK(hipEventRecord(h->ev_beg[u], h->stream));
+        if (h->run_graph) HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
+        else lio_launch_gn(h, h->run_P, Pc);
+        if (prof) HIPCHK(hipEventRecord(h->ev_end[u], h->stream));
+        HIPCHK(hipMemcpyAsync(&h->h_active[u], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->ev_chk[u], h->stream));
+        h->run_next = u + 1;
+        h->units_this_run = u + 1;
+        h->launches_this_run = (u + 1) * h->unit_iters;
+    }
+    h->run_pending = false;
+    HIPCHK(hipGetLastError());
+    return LIO_OK;
+}
+
 extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
 {
     int rc = lio_s2m_batch_begin(h);
     if (rc != LIO_OK) return rc;
-    LioIterParams P;
+    LioIterParams& P = h->run_P;
     memset(&P, 0, sizeof(P));          // (padding bytes take part in the graph-cache comparison)
     lio_fill_params(h, P, nullptr);
-    LioIterParams Pcs;
-    memset(&Pcs, 0, sizeof(Pcs));
-    const LioIterParams* Pc = nullptr;
-    if (h->corner_active && h->corner->n_blocks > 0) { lio_fill_params_corner(h, Pcs, nullptr); Pc = &Pcs; }
-    const bool prof = h->cfg.profile != 0;
-    // The GN loop (MO:1848-1859) runs ahead of the device by `lookahead` launches: after every
-    // launch (or graph replay) the count of still-iterating scans is copied to pinned memory;
-    // unit i is only enqueued once the count after unit i-1-lookahead is known to be non-zero.
-    // lookahead 0 never enqueues an empty launch; larger values keep the queue fed for small batches.
+    memset(&h->run_Pc, 0, sizeof(h->run_Pc));
+    h->run_has_c = h->corner_active && h->corner->n_blocks > 0;
+    if (h->run_has_c) lio_fill_params_corner(h, h->run_Pc, nullptr);
     int look = h->cfg.lookahead;
     if (look < 0) look = (h->total_pts >= 200000) ? 0 : 2;
     // use_graph: a unit is one replay of a captured chunk of `graph_iters` iterations
@@ -1024,30 +1075,19 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
     if (graph) {
         chunk = h->cfg.graph_iters > 0 ? h->cfg.graph_iters : 4;
         if (chunk > h->cfg.max_iters) chunk = h->cfg.max_iters;
-        if ((rc = lio_graph_prepare(h, P, Pc, chunk)) != LIO_OK) return rc;
+        if ((rc = lio_graph_prepare(h, P, h->run_has_c ? &h->run_Pc : nullptr, chunk)) != LIO_OK) return rc;
         if (h->cfg.lookahead < 0) look = 0;              // a chunk already is a run-ahead of `chunk` launches
     }
-    const int n_units = (h->cfg.max_iters + chunk - 1) / chunk;
-    int launched = 0;
-    for (int u = 0; u < n_units && u < LIO_MAX_ITERS; ++u) {          // MO:1848
-        const int chk = u - 1 - look;
-        if (chk >= 0) {
-            HIPCHK(hipEventSynchronize(h->ev_chk[chk]));
-            if (h->h_active[chk] == 0) break;
-        }
-        if (prof) HIPCHK(hipEventRecord(h->ev_beg[u], h->stream));
-        if (graph) HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
-        else lio_launch_gn(h, P, Pc);
-        if (prof) HIPCHK(hipEventRecord(h->ev_end[u], h->stream));
-        HIPCHK(hipMemcpyAsync(&h->h_active[u], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipEventRecord(h->ev_chk[u], h->stream));
-        launched += chunk;
-        h->units_this_run = u + 1;
-    }
+    h->run_graph = graph;
+    h->run_look = look;
+    h->run_units = (h->cfg.max_iters + chunk - 1) / chunk;
+    h->run_next = 0;
     h->unit_iters = chunk;
-    h->launches_this_run = launched;
-    HIPCHK(hipGetLastError());
-    return LIO_OK;
+    h->units_this_run = 0;
+    h->launches_this_run = 0;
+    h->run_pending = true;
+    // a lone registration (lio_s2m_register) has nothing to overlap with: drive the loop to the end right away
+    return lio_run_continue(h, h->defer_sync);
 }
 
 extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
@@ -1116,6 +1156,7 @@ extern "C" int lio_s2m_batch_sync(lio_s2m_handle* h)
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
+    { const int rcc = lio_run_continue(h, true); if (rcc != LIO_OK) return rcc; }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     return LIO_OK;
@@ -1127,6 +1168,7 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
     if (!h->ran) return lio_fail(LIO_ERR_ARG, "nothing has been run");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
+    { const int rcc = lio_run_continue(h, true); if (rcc != LIO_OK) return rcc; }
     if (results) {
         HIPCHK(hipMemcpyAsync(h->h_state.data(), h->d_state, (size_t)h->n_scans * sizeof(LioScanState),
                               hipMemcpyDeviceToHost, h->stream));

@@ -145,6 +145,26 @@ class ShardedRunner:
                                      if self.deterministic else None)
         self.torch.cuda.synchronize()
 
+    def upload_raw(self, base_ptr, n_pts, stride):
+        """Batch laid out back to back at `base_ptr` (pinned host or device memory), see ScanToMap.batch_upload_raw."""
+        n, g = len(n_pts), len(self.handles)
+        if n < g:
+            g = 1
+        bounds = [n * k // g for k in range(g + 1)]
+        split = [(bounds[k], bounds[k + 1]) for k in range(g)]
+        offs = np.concatenate([[0], np.cumsum(np.asarray(n_pts, np.int64) * stride)])
+        for k, ((a, b), h) in enumerate(zip(split, self.handles)):
+            h.batch_upload_raw(int(base_ptr) + int(offs[a]), list(n_pts[a:b]), stride, asynchronous=False)
+        if split != self.split or not self.sums:
+            self.split = split
+            self.sums, self.gathered = [], []
+            for k, (a, b) in enumerate(split):
+                with self.torch.cuda.stream(self.streams[k]):
+                    self.sums.append(self.torch.zeros((b - a, SUMS), dtype=self.torch.float64, device="cuda"))
+                    self.gathered.append(self.torch.zeros((self.world * (b - a), SUMS), dtype=self.torch.float64, device="cuda")
+                                         if self.deterministic else None)
+            self.torch.cuda.synchronize()
+
     def set_poses(self, poses):
         poses = np.ascontiguousarray(poses, np.float32)
         for (a, b), h in zip(self.split, self.handles):

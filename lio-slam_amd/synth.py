@@ -261,7 +261,7 @@ def make_query(boxes, true_pose, sensor="vlp16", seed=0, scan_leaf=0.4,
 
 
 def make_case(sensor="vlp16", n_keyframes=10, seed=BASE_SEED, kind="street", n_queries=1,
-              lawnmower=False, device=None, progress=None, sensor_override=None, q_range=None, with_map=True):
+              lawnmower=False, device=None, progress=None, sensor_override=None, q_range=None, with_map=True, workers=1):
     """One registration workload: map + n_queries (scan, true pose, initial guess).
 
     q_range=(a, b): only queries a..b-1 are ray-cast (the others are None) -- the ranks of a multi-GPU bench
@@ -276,16 +276,24 @@ def make_case(sensor="vlp16", n_keyframes=10, seed=BASE_SEED, kind="street", n_q
     # along the path, 0.5 m past a keyframe (the last one for q == 0); drawn for all queries up front
     ks = [n_keyframes - 1 if q == 0 else int(rng.integers(0, n_keyframes)) for q in range(n_queries)]
     a, b = q_range if q_range is not None else (0, n_queries)
-    queries = []
-    for q in range(n_queries):
-        if not (a <= q < b):
-            queries.append(None)
-            continue
+
+    def one(q):
         tp = np.array(kfs[ks[q]], np.float64)
         tp[3] += 0.5 * math.cos(tp[2])
         tp[4] += 0.5 * math.sin(tp[2])
         scan, init = make_query(boxes, tp, sensor, seed=seed + 5000 + q, device=device)
-        queries.append({"scan": scan, "pose_true": tp.astype(np.float32), "pose_init": init})
+        return {"scan": scan, "pose_true": tp.astype(np.float32), "pose_init": init}
+
+    todo = [q for q in range(n_queries) if a <= q < b]
+    if workers > 1 and len(todo) > 8:
+        # every query has its own seed, so the result does not depend on the schedule; the host half of a query
+        # (numpy sort of ~100 k points for the voxel filter) releases the GIL
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as ex:
+            done = dict(zip(todo, ex.map(one, todo)))
+    else:
+        done = {q: one(q) for q in todo}
+    queries = [done.get(q) for q in range(n_queries)]
     return {"map": map_xyz, "queries": queries, "boxes": boxes, "kf_poses": kfs, "keyframes": kept}
 
 
