@@ -30,21 +30,151 @@ def test_config2_vlp16_vs_50_keyframes(pkg, oracle, vlp16_50kf):
     s2m.close()
 
 
-def test_config3_os1_64_forced_30_iterations(pkg, oracle, synth):
-    """configs[2]: OS1-64 64x1024 scan, 30 Gauss-Newton iterations forced (the map uses 40
-    keyframes so that the CPU ray caster stays within test time; bench.py runs 200)."""
-    case = synth.make_case("os1_64", n_keyframes=40, seed=5, device="cpu", n_queries=1)
-    q = case["queries"][0]
-    s2m = pkg.ScanToMap(force_all_iters=1, max_iters=30)
-    s2m.set_map(case["map"])
-    pose, res, rc = s2m.scan2MapOptimization(q["scan"], q["pose_init"])
-    pose_o, res_o, _, _ = oracle.scan2map(oracle.default_config(knn_mode=1, n_threads=8, force_all_iters=1),
-                                          q["scan"], case["map"], q["pose_init"])
-    assert res.iters == res_o.iters == 30 and res.converged == res_o.converged == 1
-    assert list(res.n_corr_iter)[:30] == list(res_o.n_corr_iter)[:30]
-    np.testing.assert_allclose(np.array(res.pose_iter)[:30, 3:], np.array(res_o.pose_iter)[:30, 3:], atol=TOL_T)
-    np.testing.assert_allclose(np.array(res.pose_iter)[:30, :3], np.array(res_o.pose_iter)[:30, :3], atol=TOL_R)
-    s2m.close()
+def _gpu_case(synth, sensor, n_keyframes, n_queries, seed, **kw):
+    """Synthetic case ray-cast on the GPU (as bench.py does): full-size configs in seconds instead of minutes."""
+    return synth.make_case(sensor, n_keyframes=n_keyframes, seed=seed, device="cuda", n_queries=n_queries, workers=8, **kw)
+
+
+def test_config3_os1_64_vs_200_keyframes_forced_30_iterations(pkg, oracle, synth):
+    """configs[2] at size: Ouster OS1-64 64x1024 scan vs a 200-keyframe map, 30 Gauss-Newton iterations forced
+    (MO:1848 without the break MO:1857-1858): every iteration's pose and correspondence count vs the oracle."""
+    case = _gpu_case(synth, "os1_64", 200, 2, seed=5)
+    assert len(case["map"]) > 50000
+    for q in case["queries"]:
+        s2m = pkg.ScanToMap(force_all_iters=1, max_iters=30, record_corr_iter=29)
+        s2m.set_map(case["map"])
+        pose, res, rc = s2m.scan2MapOptimization(q["scan"], q["pose_init"])
+        flag, coeff, nn = s2m.get_correspondences(0)
+        pose_o, res_o, _, corr = oracle.scan2map(oracle.default_config(knn_mode=1, n_threads=8, force_all_iters=1),
+                                                 q["scan"], case["map"], q["pose_init"], corr_iter=29)
+        assert res.iters == res_o.iters == 30 and res.converged == res_o.converged == 1 and rc == res_o.status == 0
+        assert list(res.n_corr_iter)[:30] == list(res_o.n_corr_iter)[:30]
+        np.testing.assert_allclose(np.array(res.pose_iter)[:30, 3:], np.array(res_o.pose_iter)[:30, 3:], atol=TOL_T)
+        np.testing.assert_allclose(np.array(res.pose_iter)[:30, :3], np.array(res_o.pose_iter)[:30, :3], atol=TOL_R)
+        assert np.array_equal(flag, corr[0]) and np.array_equal(nn, corr[2])          # the LAST iteration's association
+        assert np.array_equal(coeff[flag == 1].view(np.uint32), corr[1][flag == 1].view(np.uint32))
+        assert np.abs(pose[3:] - q["pose_true"][3:]).max() < 0.05
+        s2m.close()
+
+
+def test_headline_512_scans_64x1800_vs_200_keyframes(pkg, oracle, synth):
+    """BASELINE headline / configs[4] at size: 512 hdl64 64x1800 scans against the 200-keyframe map through the batched
+    path with the hipGraph-captured loop.  Oracle on a fixed sample of 16 scans (flags / 5-NN / coefficients of
+    iteration 0 bit-exact, poses within tolerance); batch == single and permutation invariance on ALL 512."""
+    case = _gpu_case(synth, "hdl64", 200, 512, seed=20241022)
+    scans = [q["scan"] for q in case["queries"]]
+    poses0 = np.stack([q["pose_init"] for q in case["queries"]])
+    assert len(case["map"]) > 50000 and np.mean([len(s) for s in scans]) > 5000
+    g = pkg.ScanToMap(use_graph=1, graph_iters=12)
+    g.set_map(case["map"])
+    g.batch_upload(scans); g.batch_set_poses(poses0); g.batch_run()
+    poses, res = g.batch_results()
+    assert all(r.status == 0 and r.converged == 1 for r in res)
+    err = np.abs(poses - np.stack([q["pose_true"] for q in case["queries"]]))
+    assert err[:, 3:].max() < 0.06 and err[:, :3].max() < 0.012                # known answer for every scan
+    # (1) oracle on a fixed sample
+    sample = list(range(0, 512, 32))
+    e = pkg.ScanToMap(record_corr_iter=0)                                     # eager loop, iteration-0 association kept
+    e.set_map(case["map"])
+    e.batch_upload([scans[i] for i in sample]); e.batch_set_poses(poses0[sample]); e.batch_run()
+    pe, re_ = e.batch_results()
+    cfg = oracle.default_config(knn_mode=1, n_threads=8)
+    n_bit = 0
+    for k, i in enumerate(sample):
+        po, ro, _, corr = oracle.scan2map(cfg, scans[i], case["map"], poses0[i], corr_iter=0)
+        flag, coeff, nn = e.get_correspondences(k)
+        assert np.array_equal(flag, corr[0]) and np.array_equal(nn, corr[2])
+        assert np.array_equal(coeff[flag == 1].view(np.uint32), corr[1][flag == 1].view(np.uint32))
+        assert re_[k].iters == ro.iters == res[i].iters
+        assert np.abs(pe[k][3:] - po[3:]).max() <= TOL_T and np.abs(pe[k][:3] - po[:3]).max() <= TOL_R
+        np.testing.assert_array_equal(pe[k], poses[i])                        # small eager batch == big graph batch
+        n_bit += int(np.array_equal(pe[k], po))
+    assert n_bit >= 12                                                        # normally all 16 are bit-identical
+    # (2) permutation invariance on all 512 (bit-exact)
+    perm = np.random.default_rng(1).permutation(512)
+    g.batch_upload([scans[i] for i in perm]); g.batch_set_poses(poses0[perm]); g.batch_run()
+    pp, rp = g.batch_results()
+    np.testing.assert_array_equal(pp, poses[perm])
+    assert [r.iters for r in rp] == [res[i].iters for i in perm]
+    # (3) a batch gives what 512 single registrations give
+    one = pkg.ScanToMap()
+    one.set_map(case["map"])
+    for i in range(512):
+        p1, r1, _ = one.scan2MapOptimization(scans[i], poses0[i])
+        assert np.array_equal(p1, poses[i]) and r1.iters == res[i].iters, i
+    one.close(); e.close(); g.close()
+
+
+def _shard_worker(rank, world, port, q, path):
+    import importlib as il
+    import os as os_
+    import sys as sys_
+    root = os_.path.dirname(os_.path.dirname(os_.path.abspath(__file__)))
+    sys_.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    pk = il.import_module("lio-slam_amd")
+    mg = il.import_module("lio-slam_amd.multigpu")
+    os_.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z = np.load(path)
+        offs = np.concatenate([[0], np.cumsum(z["lens"])])
+        cat = z["scans"]
+        scans = [np.ascontiguousarray(cat[offs[i]:offs[i + 1]]) for i in range(len(z["lens"]))]
+        runner = mg.ShardedRunner(pk, z["map"], rank, world, dist, torch, mode="map", groups=2, device_id=0)
+        runner.upload(scans)
+        runner.set_poses(z["poses0"])
+        runner.run()
+        poses, res = runner.results()
+        q.put((rank, {"poses": poses, "iters": [r.iters for r in res], "status": [r.status for r in res],
+                      "n_shard": len(runner.idx)}))
+        runner.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_os1_128_vs_1000_keyframes_map_sharded(pkg, oracle, synth, tmp_path):
+    """configs[3] at size: OS1-128 128x2048 scans vs a 1000-keyframe map (lawn-mower path), the MAP sharded over two
+    ranks (gloo carries the all-reduce; both ranks share the test box's one GPU): sharded == unsharded == oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    case = _gpu_case(synth, "os1_128", 1000, 6, seed=77, lawnmower=True)
+    scans = [q["scan"] for q in case["queries"]]
+    poses0 = np.stack([q["pose_init"] for q in case["queries"]]).astype(np.float32)
+    assert len(case["map"]) > 60000 and min(len(s) for s in scans) > 10000
+    path = str(tmp_path / "cfg4.npz")
+    np.savez(path, map=case["map"], poses0=poses0, scans=np.concatenate(scans), lens=np.array([len(s) for s in scans]))
+    ref = pkg.ScanToMap()
+    ref.set_map(case["map"])
+    ref.batch_upload(scans); ref.batch_set_poses(poses0); ref.batch_run()
+    rp, rr = ref.batch_results()
+    ref.close()
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    qu = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, qu, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(qu.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = out[0], out[1]
+    np.testing.assert_array_equal(a["poses"], b["poses"])                     # every rank solves the same sums
+    assert a["iters"] == b["iters"] == [r.iters for r in rr] and a["status"] == [r.status for r in rr]
+    assert a["n_shard"] < len(case["map"]) and b["n_shard"] < len(case["map"])
+    np.testing.assert_allclose(a["poses"][:, 3:], rp[:, 3:], atol=TOL_T)
+    np.testing.assert_allclose(a["poses"][:, :3], rp[:, :3], atol=TOL_R)
+    cfg = oracle.default_config(knn_mode=1, n_threads=8)
+    for i in (0, 3, 5):                                                       # oracle sample
+        po, ro, _, _ = oracle.scan2map(cfg, scans[i], case["map"], poses0[i])
+        assert ro.iters == a["iters"][i]
+        assert np.abs(a["poses"][i][3:] - po[3:]).max() <= TOL_T and np.abs(a["poses"][i][:3] - po[:3]).max() <= TOL_R
+        assert np.abs(po[3:] - case["queries"][i]["pose_true"][3:]).max() < 0.06
 
 
 def test_config5_batched_properties(pkg, vlp16_50kf, synth):
