@@ -273,6 +273,40 @@ int  lio_deskew(const lio_deskew_config *cfg, const void *pts, size_t n, size_t 
                 const double *imuRotZ, int32_t imuPointerCur,
                 void *out, size_t out_stride_bytes, size_t *n_out);
 
+/* ---- cloud_info wire path: sensor_msgs/PointCloud2 blobs read in place ----------------------
+ * The reference moves every cloud through pcl::fromROSMsg / pcl::moveFromROSMsg (MO:440, IP:226-232) and
+ * pcl::toROSMsg (publishCloud UT:369-379); cloud_info.cloud_deskewed is such a blob (cloud_info.msg:27).  These
+ * entry points take the message's `data` pointer, `width*height` and the byte offsets of its `fields` directly.
+ * Constraints: little-endian (is_bigendian == 0); x, y, z are three consecutive FLOAT32 fields; intensity FLOAT32.
+ * ring / time variants cover the four sensor layouts cachePointCloud converts on the host (IP:226-285). */
+enum { LIO_PC2_UINT8 = 2, LIO_PC2_UINT16 = 4, LIO_PC2_INT32 = 5 };            /* sensor_msgs/PointField datatype codes */
+enum { LIO_PC2_TIME_F32_SECONDS = 0,   /* Velodyne / Livox "time": float seconds from the sweep start          */
+       LIO_PC2_TIME_U32_NS      = 1,   /* Ouster "t": dst.time = src.t * 1e-9f, IP:243                          */
+       LIO_PC2_TIME_U32_RAW     = 2,   /* Mulran "t": dst.time = static_cast<float>(src.t), IP:262              */
+       LIO_PC2_TIME_F64_STAMP   = 3 }; /* Robosense "timestamp": src.timestamp - points[0].timestamp, IP:269-281 */
+typedef struct lio_pc2_layout {
+    uint32_t point_step;      /* bytes per point (PointCloud2.point_step)                               */
+    uint32_t off_x;           /* byte offset of x; y and z follow at +4, +8                              */
+    int32_t  off_intensity;   /* FLOAT32, -1 = no such field (intensity reads as 0)                       */
+    int32_t  off_ring;        /* deskew only; the reference refuses clouds without it, IP:313-329         */
+    int32_t  ring_type;       /* LIO_PC2_UINT8 / LIO_PC2_UINT16 / LIO_PC2_INT32                           */
+    int32_t  off_time;        /* deskew only; -1 = no per-point time (deskewFlag = -1, IP:341-356)        */
+    int32_t  time_type;       /* LIO_PC2_TIME_*                                                           */
+    int32_t  pin_host;        /* 1 = hipHostRegister the blob for the duration of the call (the caller
+                                 allows its pages to be pinned): the H2D copy is then a true DMA         */
+} lio_pc2_layout;
+
+/* lio_s2m_register on the blob of cloud_info.cloud_deskewed (or any PointCloud2 with xyz): replaces
+ * pcl::fromROSMsg MO:440 + the loop MO:1848-1859.  Only off_x / point_step / pin_host of the layout are used. */
+int  lio_s2m_register_pc2(lio_s2m_handle *h, const void *data, size_t n_points, const lio_pc2_layout *layout,
+                          float pose[6], lio_s2m_result *res);
+/* lio_deskew on the raw driver message (IP:214-232 + IP:577-615).  out: PointXYZI-compatible records as for lio_deskew. */
+int  lio_deskew_pc2(const lio_deskew_config *cfg, const void *data, size_t n_points, const lio_pc2_layout *layout,
+                    double time_scan_cur,
+                    const double *imuTime, const double *imuRotX, const double *imuRotY,
+                    const double *imuRotZ, int32_t imuPointerCur,
+                    void *out, size_t out_stride_bytes, size_t *n_out);
+
 /* ---- EXTENSION beyond this reference: the range-image build -------------------------------
  * BASELINE.json's north_star names "imageProjection's deskew/range-image build"; this fork's
  * projectPointCloud IP:577-615 no longer builds one and nothing in the fork fills
@@ -361,6 +395,12 @@ int  lio_kf_store_create(int32_t device_id, lio_kf_store **out);
 void lio_kf_store_destroy(lio_kf_store *s);
 int  lio_kf_store_add(lio_kf_store *s, const void *cloud, size_t n, size_t stride_bytes, int32_t *id_out);
 int  lio_kf_store_count(const lio_kf_store *s);
+/* The same from DEVICE memory (x,y,z @0,4,8, intensity @16 when stride >= 20, else 0): no host round trip. */
+int  lio_kf_store_add_device(lio_kf_store *s, const void *d_cloud, size_t n, size_t stride_bytes, int32_t *id_out);
+/* saveKeyFramesAndFactor MO:2136-2142 (`pcl::copyPointCloud(*laserCloudSurfLastDS, *thisSurfKeyFrame);
+ * surfCloudKeyFrames.push_back(thisSurfKeyFrame)`): appends the scan that batch slot `scan` of `h` has just
+ * registered (its records are still staged on the device) as a keyframe -- no D2H, no H2D. */
+int  lio_kf_store_add_from_handle(lio_kf_store *s, lio_s2m_handle *h, int32_t scan, int32_t *id_out);
 int  lio_assemble_map_resident(lio_s2m_handle *h, lio_kf_store *s, int32_t n_selected, const int32_t *ids,
                                const float *poses, float leaf, void *out, size_t out_stride_bytes, size_t *n_out);
 

@@ -75,6 +75,16 @@ class RangeImageConfig(C.Structure):
                 ("device_id", C.c_int32)]
 
 
+class PC2Layout(C.Structure):
+    """Field layout of a sensor_msgs/PointCloud2 (include/liogpu.h lio_pc2_layout)."""
+    _fields_ = [("point_step", C.c_uint32), ("off_x", C.c_uint32), ("off_intensity", C.c_int32), ("off_ring", C.c_int32),
+                ("ring_type", C.c_int32), ("off_time", C.c_int32), ("time_type", C.c_int32), ("pin_host", C.c_int32)]
+
+
+PC2_UINT8, PC2_UINT16, PC2_INT32 = 2, 4, 5
+PC2_TIME_F32_SECONDS, PC2_TIME_U32_NS, PC2_TIME_U32_RAW, PC2_TIME_F64_STAMP = 0, 1, 2, 3
+
+
 class FeatureConfig(C.Structure):
     _fields_ = [("N_SCAN", C.c_int32), ("edgeThreshold", C.c_float), ("surfThreshold", C.c_float),
                 ("surfLeafSize", C.c_float), ("device_id", C.c_int32)]
@@ -112,7 +122,7 @@ EXPORTS = [
     "lio_s2m_get_corner_correspondences", "lio_feature_default_config", "lio_extract_features",
     "lio_range_image_default_config", "lio_range_image",
     "lio_s2m_share_map", "lio_s2m_batch_upload_async", "lio_host_alloc", "lio_host_free", "lio_host_register",
-    "lio_host_unregister",
+    "lio_host_unregister", "lio_s2m_register_pc2", "lio_deskew_pc2", "lio_kf_store_add_device", "lio_kf_store_add_from_handle",
 ]
 
 
@@ -136,6 +146,7 @@ def load_library():
     L.lio_s2m_destroy.restype = None
     L.lio_s2m_set_map.argtypes = [vp, vp, sz, sz]
     L.lio_s2m_register.argtypes = [vp, vp, sz, sz, C.POINTER(f32), C.POINTER(S2MResult)]
+    L.lio_s2m_register_pc2.argtypes = [vp, vp, sz, C.POINTER(PC2Layout), C.POINTER(f32), C.POINTER(S2MResult)]
     L.lio_s2m_batch_upload.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), sz]
     L.lio_s2m_batch_upload_async.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), sz]
     L.lio_s2m_share_map.argtypes = [vp, vp]
@@ -173,6 +184,8 @@ def load_library():
     L.lio_imu_deskew_info.argtypes = [dp, dp, dp, dp, i32, f64, f64, dp, dp, dp, dp]
     L.lio_deskew.argtypes = [C.POINTER(DeskewConfig), vp, sz, sz, f64, dp, dp, dp, dp, i32, vp, sz,
                              C.POINTER(sz)]
+    L.lio_deskew_pc2.argtypes = [C.POINTER(DeskewConfig), vp, sz, C.POINTER(PC2Layout), f64, dp, dp, dp, dp, i32, vp, sz,
+                                 C.POINTER(sz)]
     L.lio_curvature.argtypes = [i32, vp, sz, vp, vp, vp]
     L.lio_range_image_default_config.argtypes = [C.POINTER(RangeImageConfig)]
     L.lio_range_image_default_config.restype = None
@@ -189,6 +202,8 @@ def load_library():
     L.lio_kf_store_destroy.restype = None
     L.lio_kf_store_add.argtypes = [vp, vp, sz, sz, C.POINTER(i32)]
     L.lio_kf_store_count.argtypes = [vp]
+    L.lio_kf_store_add_device.argtypes = [vp, vp, sz, sz, C.POINTER(i32)]
+    L.lio_kf_store_add_from_handle.argtypes = [vp, vp, i32, C.POINTER(i32)]
     L.lio_assemble_map_resident.argtypes = [vp, vp, i32, C.POINTER(i32), C.POINTER(f32), f32, vp, sz, C.POINTER(sz)]
     L.lio_assemble_map.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(sz), sz, C.POINTER(f32), f32, vp, sz,
                                    C.POINTER(sz)]
@@ -255,6 +270,16 @@ class ScanToMap:
         rc = _check(self.lib.lio_s2m_register(self.h, a.ctypes.data, len(a), stride, _f32p(p), C.byref(res)),
                     "lio_s2m_register")
         self._n_scans, self._npts = 1, [len(a)]
+        return p, res, rc
+
+    # pcl::fromROSMsg(msgIn->cloud_deskewed, ...) MO:440 + scan2MapOptimization on the PointCloud2 blob itself
+    def scan2MapOptimizationPC2(self, blob, n_points, layout, pose):
+        b = np.ascontiguousarray(blob).view(np.uint8).reshape(-1)
+        p = np.array(pose, np.float32).copy()
+        res = S2MResult()
+        rc = _check(self.lib.lio_s2m_register_pc2(self.h, b.ctypes.data, n_points, C.byref(layout), _f32p(p), C.byref(res)),
+                    "lio_s2m_register_pc2")
+        self._n_scans, self._npts = 1, [n_points]
         return p, res, rc
 
     # batched form
@@ -485,6 +510,20 @@ def deskew(dcfg, records, t_cur, imu):
     return np.concatenate([o[:, :3], o[:, 4:5]], axis=1).copy()
 
 
+def deskew_pc2(dcfg, blob, n_points, layout, t_cur, imu):
+    """projectPointCloud on the raw PointCloud2 `data` blob (any of the four sensor layouts of IP:226-285)."""
+    cur, T, RX, RY, RZ = imu
+    L = load_library()
+    b = np.ascontiguousarray(blob).view(np.uint8).reshape(-1)
+    out = _scratch("deskew", (max(n_points, 1), 8))
+    n_out = C.c_size_t()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    _check(L.lio_deskew_pc2(C.byref(dcfg), b.ctypes.data, n_points, C.byref(layout), t_cur,
+                            dp(T), dp(RX), dp(RY), dp(RZ), cur, out.ctypes.data, 32, C.byref(n_out)), "lio_deskew_pc2")
+    o = out[:n_out.value]
+    return np.concatenate([o[:, :3], o[:, 4:5]], axis=1).copy()
+
+
 def deskew_default_config(**kw):
     c = DeskewConfig()
     load_library().lio_deskew_default_config(C.byref(c))
@@ -616,6 +655,16 @@ class KeyframeStore:
         rec = _as_xyzi_records(cloud_xyzi)
         kid = C.c_int32()
         _check(self.lib.lio_kf_store_add(self.h, rec.ctypes.data, len(rec), 32, C.byref(kid)), "lio_kf_store_add")
+        return kid.value
+
+    def add_from_handle(self, s2m, scan=0):         # MO:2136-2142 without leaving the device
+        kid = C.c_int32()
+        _check(self.lib.lio_kf_store_add_from_handle(self.h, s2m.h, scan, C.byref(kid)), "lio_kf_store_add_from_handle")
+        return kid.value
+
+    def add_device(self, dev_ptr, n, stride):
+        kid = C.c_int32()
+        _check(self.lib.lio_kf_store_add_device(self.h, C.c_void_p(dev_ptr), n, stride, C.byref(kid)), "lio_kf_store_add_device")
         return kid.value
 
     def __len__(self):

@@ -450,12 +450,8 @@ extern "C" void lio_kf_store_destroy(lio_kf_store* s)
 
 extern "C" int lio_kf_store_count(const lio_kf_store* s) { return s ? (int)s->off.size() : 0; }
 
-extern "C" int lio_kf_store_add(lio_kf_store* s, const void* cloud, size_t n, size_t stride, int32_t* id_out)
+static int kf_store_reserve(lio_kf_store* s, size_t n)
 {
-    if (!s || (n && !cloud)) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
-    if (stride < 20 || (stride & 3)) return lio_fail_ext(LIO_ERR_ARG, "stride must be >= 20 and a multiple of 4", hipSuccess);
-    int rc = check_device(s->device_id);
-    if (rc != LIO_OK) return rc;
     if (s->used + n > 0x7fffffffull - 1024) return lio_fail_ext(LIO_ERR_CAPACITY, "keyframe store is full", hipSuccess);
     if (s->used + n > s->cap) {                         // grow geometrically, keep the resident clouds
         size_t ncap = (s->cap ? s->cap * 2 : (size_t)1 << 20);
@@ -467,19 +463,90 @@ extern "C" int lio_kf_store_add(lio_kf_store* s, const void* cloud, size_t n, si
         s->d_pts = np_;
         s->cap = ncap;
     }
+    return LIO_OK;
+}
+
+static void kf_store_commit(lio_kf_store* s, size_t n, int32_t* id_out)
+{
+    if (id_out) *id_out = (int32_t)s->off.size();
+    s->off.push_back(s->used);
+    s->cnt.push_back(n);
+    s->used += n;
+}
+
+// records (x,y,z at xyz_off, intensity at byte 16 when the record has one) -> float4 (x,y,z,intensity)
+__global__ void k_rec_to_xyzi4(const unsigned char* __restrict__ src, size_t stride, size_t xyz_off, int has_intensity, int n,
+                               float4* __restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char* rec = src + (size_t)i * stride;
+    const float* p = reinterpret_cast<const float*>(rec + xyz_off);
+    dst[i] = make_float4(p[0], p[1], p[2], has_intensity ? *reinterpret_cast<const float*>(rec + 16) : 0.0f);
+}
+
+extern "C" int lio_kf_store_add(lio_kf_store* s, const void* cloud, size_t n, size_t stride, int32_t* id_out)
+{
+    if (!s || (n && !cloud)) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
+    if (stride < 20 || (stride & 3)) return lio_fail_ext(LIO_ERR_ARG, "stride must be >= 20 and a multiple of 4", hipSuccess);
+    int rc = check_device(s->device_id);
+    if (rc != LIO_OK) return rc;
+    if ((rc = kf_store_reserve(s, n)) != LIO_OK) return rc;
     if (n) {
         Buf raw;
         HIPCHK(raw.alloc(n * stride));
-        HIPCHK(hipMemcpyAsync(raw.p, cloud, n * stride, hipMemcpyHostToDevice, nullptr));
+        HIPCHK(hipMemcpyAsync(raw.p, cloud, n * stride, hipMemcpyDefault, nullptr));
         hipLaunchKernelGGL(k_aos_to_xyzi4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
                            raw.as<unsigned char>(), stride, (int)n, s->d_pts + s->used);
         HIPCHK(hipStreamSynchronize(nullptr));
         HIPCHK(hipGetLastError());
     }
-    if (id_out) *id_out = (int32_t)s->off.size();
-    s->off.push_back(s->used);
-    s->cnt.push_back(n);
-    s->used += n;
+    kf_store_commit(s, n, id_out);
+    return LIO_OK;
+}
+
+extern "C" int lio_kf_store_add_device(lio_kf_store* s, const void* d_cloud, size_t n, size_t stride, int32_t* id_out)
+{
+    if (!s || (n && !d_cloud)) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
+    if (stride < 12 || (stride & 3)) return lio_fail_ext(LIO_ERR_ARG, "stride must be >= 12 and a multiple of 4", hipSuccess);
+    int rc = check_device(s->device_id);
+    if (rc != LIO_OK) return rc;
+    if ((rc = kf_store_reserve(s, n)) != LIO_OK) return rc;
+    if (n) {
+        HIPCHK(hipDeviceSynchronize());                  // the producer of d_cloud may have used any stream
+        hipLaunchKernelGGL(k_rec_to_xyzi4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
+                           (const unsigned char*)d_cloud, stride, (size_t)0, stride >= 20 ? 1 : 0, (int)n, s->d_pts + s->used);
+        HIPCHK(hipStreamSynchronize(nullptr));
+        HIPCHK(hipGetLastError());
+    }
+    kf_store_commit(s, n, id_out);
+    return LIO_OK;
+}
+
+int lio_s2m_staged_scan(lio_s2m_handle* h, int scan, const unsigned char** d_rec, size_t* n, size_t* stride, size_t* xyz_off,
+                        int* device_id, hipStream_t* stream);   // liogpu_api.hip
+
+extern "C" int lio_kf_store_add_from_handle(lio_kf_store* s, lio_s2m_handle* h, int32_t scan, int32_t* id_out)
+{
+    if (!s || !h) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
+    const unsigned char* rec = nullptr;
+    size_t n = 0, stride = 0, xyz_off = 0;
+    int dev = 0;
+    hipStream_t st = nullptr;
+    int rc = lio_s2m_staged_scan(h, scan, &rec, &n, &stride, &xyz_off, &dev, &st);
+    if (rc != LIO_OK) return rc;
+    if (dev != s->device_id) return lio_fail_ext(LIO_ERR_ARG, "the handle and the keyframe store live on different devices", hipSuccess);
+    if ((rc = check_device(s->device_id)) != LIO_OK) return rc;
+    if ((rc = kf_store_reserve(s, n)) != LIO_OK) return rc;
+    if (n) {
+        // (PCL-style records keep the intensity at byte 16; packed xyz / xyzi-at-12 records carry none there)
+        const int has_i = (xyz_off == 0 && stride >= 20) ? 1 : 0;
+        hipLaunchKernelGGL(k_rec_to_xyzi4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rec, stride, xyz_off, has_i, (int)n,
+                           s->d_pts + s->used);
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
+    }
+    kf_store_commit(s, n, id_out);
     return LIO_OK;
 }
 

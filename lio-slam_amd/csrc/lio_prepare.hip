@@ -32,7 +32,41 @@ struct LioDeskewParams {
     double time_scan_cur;
     const double* imuTime; const double* imuRotX; const double* imuRotY; const double* imuRotZ;
     int imuPointerCur;
+    // field layout of a record (sensor_msgs/PointCloud2 `fields`); the PointXYZIRT defaults are 0 / 16 / 20 / 24
+    int off_xyz, off_intensity, off_ring, off_time;   // byte offsets; off_intensity / off_time < 0: absent
+    int ring_type;              // 0 = uint16 (Velodyne, Robosense), 1 = uint8 (Ouster), 2 = int32 (Mulran)
+    int time_type;              // 0 = float seconds; 1 = uint32 ns -> t * 1e-9f (IP:243); 2 = uint32 -> (float)t (IP:262);
+                                // 3 = double stamp minus the first point's (IP:281)
 };
+
+// The fields of record i as cachePointCloud IP:226-285 hands them to projectPointCloud (Velodyne layout).
+LIO_DEV void lio_rec_xyzi(const LioDeskewParams& P, const unsigned char* rec, float& x, float& y, float& z, float& inten)
+{
+    const float* f = reinterpret_cast<const float*>(rec + P.off_xyz);
+    x = f[0]; y = f[1]; z = f[2];
+    inten = P.off_intensity >= 0 ? *reinterpret_cast<const float*>(rec + P.off_intensity) : 0.0f;
+}
+LIO_DEV int lio_rec_ring(const LioDeskewParams& P, const unsigned char* rec)
+{
+    const unsigned char* r = rec + P.off_ring;
+    if (P.ring_type == 1) return (int)*r;
+    if (P.ring_type == 2) return (int)(unsigned short)*reinterpret_cast<const int*>(r);   // `dst.ring = src.ring` narrows to uint16_t, IP:261
+    return (int)*reinterpret_cast<const unsigned short*>(r);
+}
+LIO_DEV float lio_rec_time(const LioDeskewParams& P, const unsigned char* rec)
+{
+    if (P.off_time < 0) return 0.0f;
+    const unsigned char* t = rec + P.off_time;
+    if (P.time_type == 1) return (float)*reinterpret_cast<const unsigned*>(t) * 1e-9f;          // IP:243
+    if (P.time_type == 2) return (float)*reinterpret_cast<const unsigned*>(t);                   // IP:262
+    if (P.time_type == 3) {                                                                      // IP:269, 281
+        double t0, ti;                                   // (8-byte fields of a PointCloud2 need not be 8-byte aligned)
+        memcpy(&t0, P.pts + P.off_time, 8);
+        memcpy(&ti, t, 8);
+        return (float)(ti - t0);
+    }
+    return *reinterpret_cast<const float*>(t);
+}
 
 LIO_DEV float lio_sinf64(float x) { return (float)sin((double)x); }
 LIO_DEV float lio_cosf64(float x) { return (float)cos((double)x); }
@@ -108,9 +142,9 @@ __global__ __launch_bounds__(256) void k_deskew_flags(LioDeskewParams P, unsigne
     bool k = false;
     if (i < P.n) {
         const unsigned char* rec = P.pts + (size_t)i * P.stride;
-        const float* f = reinterpret_cast<const float*>(rec);
-        const int ring = *reinterpret_cast<const unsigned short*>(rec + 20);
-        k = lio_keep_point(P, i, f[0], f[1], f[2], f[4], ring);
+        float fx, fy, fz, fi;
+        lio_rec_xyzi(P, rec, fx, fy, fz, fi);
+        k = lio_keep_point(P, i, fx, fy, fz, fi, lio_rec_ring(P, rec));
         keep[i] = k ? 1 : 0;
     }
     const unsigned long long m = __ballot(k);
@@ -174,7 +208,7 @@ __global__ __launch_bounds__(256) void k_deskew_emit(LioDeskewParams P, const un
         const int fi = *first_idx;
         float inv[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
         if (fi < P.n) {
-            const float tf = *reinterpret_cast<const float*>(P.pts + (size_t)fi * P.stride + 24);
+            const float tf = lio_rec_time(P, P.pts + (size_t)fi * P.stride);
             float rx, ry, rz, L[9];
             lio_find_rotation(P.time_scan_cur + (double)tf, sT, sX, sY, sZ, P.imuPointerCur, rx, ry, rz);
             lio_rot_rpy(rx, ry, rz, L);
@@ -194,12 +228,12 @@ __global__ __launch_bounds__(256) void k_deskew_emit(LioDeskewParams P, const un
     for (int w = 0; w < wave; ++w) pos += s_cnt[w];
 
     const unsigned char* rec = P.pts + (size_t)i * P.stride;
-    const float* f = reinterpret_cast<const float*>(rec);
-    const float px = f[0], py = f[1], pz = f[2], pi = f[4];
+    float px, py, pz, pi;
+    lio_rec_xyzi(P, rec, px, py, pz, pi);
     float ox = px, oy = py, oz = pz;
     if (P.do_deskew) {
         float rx, ry, rz, L[9], Bt[9];
-        lio_find_rotation(P.time_scan_cur + (double)f[6], sT, sX, sY, sZ, P.imuPointerCur, rx, ry, rz);  // IP:550-553
+        lio_find_rotation(P.time_scan_cur + (double)lio_rec_time(P, rec), sT, sX, sY, sZ, P.imuPointerCur, rx, ry, rz);  // IP:550-553
         lio_rot_rpy(rx, ry, rz, L);                                                                      // IP:565
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -250,7 +284,7 @@ __global__ __launch_bounds__(256) void k_ri_first(LioRangeImageParams P, int* __
     const unsigned char* rec = P.d.pts + (size_t)i * P.d.stride;
     const float* f = reinterpret_cast<const float*>(rec);
     float range;
-    const int cell = lio_ri_cell(P, f[0], f[1], f[2], *reinterpret_cast<const unsigned short*>(rec + 20), range);
+    const int cell = lio_ri_cell(P, f[0], f[1], f[2], lio_rec_ring(P.d, rec), range);
     if (cell < 0) return;
     atomicMin(&cell_first[cell], i);
     atomicMin(first_idx, i);
@@ -278,7 +312,7 @@ __global__ __launch_bounds__(256) void k_ri_extract(LioRangeImageParams P, const
         const int fi = *first_idx;                           // firstPointFlag: the first point that reaches deskewPoint
         float inv[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
         if (fi < P.d.n) {
-            const float tf = *reinterpret_cast<const float*>(P.d.pts + (size_t)fi * P.d.stride + 24);
+            const float tf = lio_rec_time(P.d, P.d.pts + (size_t)fi * P.d.stride);
             float rx, ry, rz, L[9];
             lio_find_rotation(P.d.time_scan_cur + (double)tf, sT, sX, sY, sZ, P.d.imuPointerCur, rx, ry, rz);
             lio_rot_rpy(rx, ry, rz, L);
@@ -375,14 +409,86 @@ extern "C" void lio_deskew_default_config(lio_deskew_config* c)
 
 typedef LioTemp DevBuf;      // temporaries come from the recycling pool (lio_pool.h)
 
+static const lio_pc2_layout kXyzirtLayout = { 32, 0, 16, 20, LIO_PC2_UINT16, 24, LIO_PC2_TIME_F32_SECONDS, 0 };
+
+static int lio_check_layout(const lio_pc2_layout* L, bool need_ring)
+{
+    if (!L) return lio_fail_ext(LIO_ERR_ARG, "null layout", hipSuccess);
+    const uint32_t st = L->point_step;
+    if (st < 12 || (L->off_x & 3) || L->off_x + 12 > st)
+        return lio_fail_ext(LIO_ERR_ARG, "x, y, z must be three consecutive FLOAT32 fields inside the record", hipSuccess);
+    if (L->off_intensity >= 0 && ((L->off_intensity & 3) || (uint32_t)L->off_intensity + 4 > st))
+        return lio_fail_ext(LIO_ERR_ARG, "intensity must be an aligned FLOAT32 field inside the record", hipSuccess);
+    if (need_ring) {
+        const int rs = L->ring_type == LIO_PC2_UINT8 ? 1 : (L->ring_type == LIO_PC2_UINT16 ? 2 : (L->ring_type == LIO_PC2_INT32 ? 4 : 0));
+        if (!rs || L->off_ring < 0 || (L->off_ring % rs) || (uint32_t)L->off_ring + rs > st)
+            return lio_fail_ext(LIO_ERR_ARG, "ring must be an aligned UINT8 / UINT16 / INT32 field inside the record (IP:313-329)", hipSuccess);
+        if (L->off_time >= 0) {
+            const int ts = L->time_type == LIO_PC2_TIME_F64_STAMP ? 8 : 4;
+            if (L->time_type < 0 || L->time_type > 3 || (L->off_time & 3) || (uint32_t)L->off_time + ts > st)
+                return lio_fail_ext(LIO_ERR_ARG, "time field outside the record or of an unknown type", hipSuccess);
+        }
+    }
+    return LIO_OK;
+}
+
+static void lio_fill_layout(LioDeskewParams& P, const lio_pc2_layout& L)
+{
+    P.off_xyz = (int)L.off_x; P.off_intensity = L.off_intensity; P.off_ring = L.off_ring; P.off_time = L.off_time;
+    P.ring_type = L.ring_type == LIO_PC2_UINT8 ? 1 : (L.ring_type == LIO_PC2_INT32 ? 2 : 0);
+    P.time_type = L.time_type;
+}
+
+static int lio_deskew_impl(const lio_deskew_config* cfg, const void* pts, size_t n, const lio_pc2_layout& L,
+                           double time_scan_cur,
+                           const double* imuTime, const double* imuRotX, const double* imuRotY,
+                           const double* imuRotZ, int32_t imuPointerCur,
+                           void* out, size_t out_stride, size_t* n_out);
+
 extern "C" int lio_deskew(const lio_deskew_config* cfg, const void* pts, size_t n, size_t stride,
                           double time_scan_cur,
                           const double* imuTime, const double* imuRotX, const double* imuRotY,
                           const double* imuRotZ, int32_t imuPointerCur,
                           void* out, size_t out_stride, size_t* n_out)
 {
+    if (stride < 28 || (stride & 3))
+        return lio_fail_ext(LIO_ERR_ARG, "PointXYZIRT stride must be >= 28, output stride >= 20, multiples of 4", hipSuccess);
+    lio_pc2_layout L = kXyzirtLayout;
+    L.point_step = (uint32_t)stride;
+    return lio_deskew_impl(cfg, pts, n, L, time_scan_cur, imuTime, imuRotX, imuRotY, imuRotZ, imuPointerCur, out, out_stride, n_out);
+}
+
+// projectPointCloud IP:577-615 straight from the `data` blob of the incoming sensor_msgs/PointCloud2: replaces
+// pcl::moveFromROSMsg and the per-sensor conversion loops of cachePointCloud IP:226-285 as well.
+extern "C" int lio_deskew_pc2(const lio_deskew_config* cfg, const void* data, size_t n_points, const lio_pc2_layout* layout,
+                              double time_scan_cur,
+                              const double* imuTime, const double* imuRotX, const double* imuRotY,
+                              const double* imuRotZ, int32_t imuPointerCur,
+                              void* out, size_t out_stride, size_t* n_out)
+{
+    const int rc = lio_check_layout(layout, true);
+    if (rc != LIO_OK) return rc;
+    lio_deskew_config c2;
+    if (cfg) { c2 = *cfg; if (layout->off_time < 0) c2.deskew_flag = -1; }   // no per-point time field: IP:341-356 sets deskewFlag = -1
+    bool pinned = false;
+    if (layout->pin_host && data && n_points)
+        pinned = hipHostRegister(const_cast<void*>(data), n_points * layout->point_step, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    const int r = lio_deskew_impl(cfg ? &c2 : nullptr, data, n_points, *layout, time_scan_cur, imuTime, imuRotX, imuRotY, imuRotZ,
+                                  imuPointerCur, out, out_stride, n_out);
+    if (pinned) (void)hipHostUnregister(const_cast<void*>(data));
+    return r;
+}
+
+static int lio_deskew_impl(const lio_deskew_config* cfg, const void* pts, size_t n, const lio_pc2_layout& L,
+                           double time_scan_cur,
+                           const double* imuTime, const double* imuRotX, const double* imuRotY,
+                           const double* imuRotZ, int32_t imuPointerCur,
+                           void* out, size_t out_stride, size_t* n_out)
+{
+    const size_t stride = L.point_step;
     if (!cfg || !n_out || (n && (!pts || !out))) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
-    if (stride < 28 || (stride & 3) || out_stride < 20 || (out_stride & 3))
+    if (out_stride < 20 || (out_stride & 3))
         return lio_fail_ext(LIO_ERR_ARG, "PointXYZIRT stride must be >= 28, output stride >= 20, multiples of 4", hipSuccess);
     if (cfg->downsampleRate < 1 || cfg->point_filter_num < 1)
         return lio_fail_ext(LIO_ERR_ARG, "downsampleRate and point_filter_num must be >= 1", hipSuccess);
@@ -409,7 +515,7 @@ extern "C" int lio_deskew(const lio_deskew_config* cfg, const void* pts, size_t 
     HIPCHK(d_imu.alloc(sizeof(double) * 4 * (size_t)(nt ? nt : 1)));
     HIPCHK(d_out.alloc(n * out_stride));
     hipStream_t s = nullptr;
-    HIPCHK(hipMemcpyAsync(d_pts.p, pts, n * stride, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_pts.p, pts, n * stride, hipMemcpyDefault, s));
     double* di = d_imu.as<double>();
     if (nt) {
         HIPCHK(hipMemcpyAsync(di, imuTime, sizeof(double) * nt, hipMemcpyHostToDevice, s));
@@ -423,6 +529,7 @@ extern "C" int lio_deskew(const lio_deskew_config* cfg, const void* pts, size_t 
 
     LioDeskewParams P;
     P.pts = d_pts.as<unsigned char>(); P.stride = stride; P.n = (int)n;
+    lio_fill_layout(P, L);
     P.N_SCAN = cfg->N_SCAN; P.downsampleRate = cfg->downsampleRate; P.point_filter_num = cfg->point_filter_num;
     P.minFront = cfg->lidarMinFront; P.minBack = cfg->lidarMinBack; P.minLeft = cfg->lidarMinLeft;
     P.minRight = cfg->lidarMinRight; P.maxRange = cfg->lidarMaxRange; P.maxIntensity = cfg->lidarMaxIntensity;
@@ -546,6 +653,7 @@ extern "C" int lio_range_image(const lio_range_image_config* cfg, const void* pt
 
     LioRangeImageParams P;
     P.d.pts = d_pts.as<unsigned char>(); P.d.stride = stride; P.d.n = (int)n;
+    P.d.off_xyz = 0; P.d.off_intensity = 16; P.d.off_ring = 20; P.d.off_time = 24; P.d.ring_type = 0; P.d.time_type = 0;
     P.d.N_SCAN = ns; P.d.downsampleRate = cfg->downsampleRate; P.d.point_filter_num = 1;
     P.d.minFront = P.d.minBack = P.d.minLeft = P.d.minRight = 0.0f;
     P.d.maxRange = cfg->lidarMaxRange; P.d.maxIntensity = 0.0f;

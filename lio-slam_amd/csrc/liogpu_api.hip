@@ -101,6 +101,9 @@ struct lio_s2m_handle {
     unsigned* d_scan_bbox = nullptr; size_t cap_scan_bbox = 0;   // [n_scans][6] ordered-uint bounding boxes
     unsigned* h_scan_bbox = nullptr; size_t cap_h_scan_bbox = 0; // pinned mirror
     bool sorted = false;
+    const unsigned char* last_stage = nullptr;   // the records of the resident batch as uploaded (d_stage, or the caller's device buffer)
+    size_t last_stride = 0, last_xyz_off = 0;
+    size_t xyz_off = 0;                  // byte offset of x inside a record for the NEXT upload (lio_s2m_register_pc2)
     lio_s2m_handle* map_src = nullptr;   // lio_s2m_share_map: the handle whose resident map this one searches
     unsigned long long map_epoch = 0;    // bumped by every set_map
     float* d_nn_cache = nullptr; size_t cap_nn_cache = 0;   // [total_pts] squared 5th-neighbour distance of the previous GN iteration
@@ -638,6 +641,9 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
             }
         }
     }
+    h->last_stage = stage; h->last_stride = stride; h->last_xyz_off = h->xyz_off;
+    stage += h->xyz_off;                                 // (x, y, z are read at +0, +4, +8 from here; xyz_off + 12 <= stride)
+    h->xyz_off = 0;
     h->v_first_orig.assign((size_t)n_scans + 1, 0);
     for (const LioBlockDesc& b : blocks) h->v_first_orig[b.scan + 1]++;
     for (int s = 0; s < n_scans; ++s) h->v_first_orig[s + 1] += h->v_first_orig[s];
@@ -1280,6 +1286,40 @@ extern "C" int lio_s2m_register(lio_s2m_handle* h, const void* scan, size_t n, s
     lio_s2m_result local;
     if ((rc = lio_s2m_batch_results(h, pose, res ? res : &local)) != LIO_OK) return rc;
     return (res ? res : &local)->status;
+}
+
+// lio_s2m_register on a sensor_msgs/PointCloud2 `data` blob (cloud_info.cloud_deskewed, cloud_info.msg:27): what
+// pcl::fromROSMsg(msgIn->cloud_deskewed, *laserCloudSurfLast) MO:440 + scan2MapOptimization do, without the copy
+// into a pcl::PointCloud.  x, y, z are read in place at layout->off_x.
+extern "C" int lio_s2m_register_pc2(lio_s2m_handle* h, const void* data, size_t n_points, const lio_pc2_layout* layout,
+                                    float pose[6], lio_s2m_result* res)
+{
+    if (!h || !layout || !pose) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (layout->point_step < 12 || (layout->point_step & 3) || (layout->off_x & 3) || layout->off_x + 12 > layout->point_step)
+        return lio_fail(LIO_ERR_ARG, "x, y, z must be three consecutive FLOAT32 fields inside the record");
+    bool pinned = false;
+    if (layout->pin_host && data && n_points) {
+        HIPCHK(hipSetDevice(h->cfg.device_id));
+        pinned = hipHostRegister(const_cast<void*>(data), n_points * layout->point_step, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    h->xyz_off = layout->off_x;
+    const int rc = lio_s2m_register(h, data, n_points, layout->point_step, pose, res);
+    h->xyz_off = 0;
+    if (pinned) (void)hipHostUnregister(const_cast<void*>(data));
+    return rc;
+}
+
+// Internal (lio_mapbuild.hip): the staged records of batch slot `scan` as they were uploaded.
+int lio_s2m_staged_scan(lio_s2m_handle* h, int scan, const unsigned char** d_rec, size_t* n, size_t* stride, size_t* xyz_off,
+                        int* device_id, hipStream_t* stream)
+{
+    if (!h || scan < 0 || scan >= h->n_scans || !h->last_stage) return lio_fail(LIO_ERR_ARG, "no such resident scan");
+    const LioScanState& st = h->h_state[scan];
+    *d_rec = h->last_stage + (size_t)st.offset * h->last_stride;
+    *n = (size_t)st.n_pts; *stride = h->last_stride; *xyz_off = h->last_xyz_off;
+    *device_id = h->cfg.device_id; *stream = h->stream;
+    return LIO_OK;
 }
 
 extern "C" int lio_s2m_register_cs(lio_s2m_handle* h, const void* corner_scan, size_t n_corner,
