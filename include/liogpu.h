@@ -88,6 +88,13 @@ typedef struct lio_s2m_config {
     int32_t pipeline;        /* 0 / 1 = one fused launch per GN iteration (k_s2m_iterate); 2 = split: neighbour
                                 certificate / candidate scan / fit as three launches (identical results;
                                 measured slower on MI355X, kept as an option with its evidence)          */
+    int32_t n_devices;       /* 1 (default) = the single device `device_id`.  > 1: in-library multi-GPU -- the local
+                                map is cut into slabs (+ one-cell halo) over device_ids[0..n_devices), every
+                                registration's points are processed by the device owning their map cell and the
+                                6x6 JtJ / 6x1 Jtr / N_c are summed across the devices once per GN iteration
+                                (the join of the OpenMP loop MO:1622-1686); set_map / register / batch_* work
+                                unchanged on such a handle, so a patched node needs no other change              */
+    int32_t device_ids[8];   /* HIP device ordinals of the multi-GPU mode (an ordinal may repeat)               */
 } lio_s2m_config;
 
 /* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in

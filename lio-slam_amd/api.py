@@ -33,7 +33,7 @@ class S2MConfig(C.Structure):
         ("profile", C.c_int32), ("lookahead", C.c_int32), ("use_lds", C.c_int32), ("sort_scan", C.c_int32),
         ("cell_div", C.c_int32), ("xcd_remap", C.c_int32), ("tile_size", C.c_float),
         ("use_graph", C.c_int32), ("graph_iters", C.c_int32), ("sort_batch", C.c_int32), ("nn_cache", C.c_int32),
-        ("pipeline", C.c_int32),
+        ("pipeline", C.c_int32), ("n_devices", C.c_int32), ("device_ids", C.c_int32 * 8),
     ]
 
 
@@ -240,6 +240,10 @@ class ScanToMap:
         for k, v in cfg_overrides.items():
             if not hasattr(self.cfg, k):
                 raise AttributeError(k)
+            if k == "device_ids":
+                for i, d in enumerate(v):
+                    self.cfg.device_ids[i] = int(d)
+                continue
             setattr(self.cfg, k, v)
         self.h = C.c_void_p()
         _check(self.lib.lio_s2m_create(C.byref(self.cfg), C.byref(self.h)), "lio_s2m_create")

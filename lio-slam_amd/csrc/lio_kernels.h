@@ -30,6 +30,7 @@ struct LioIterParams {
     int* rec_nn;
     float* d5_cache;               // [total_pts] squared 5th-neighbour distance of the previous iteration (-1: none), or null
     long long* stamps;             // diagnostic phase clock: [block][wave][8] cycle counters, or null
+    const unsigned char* blk_skip; // map sharding: [n_blocks] workgroups k_shard_cull has already answered for, or null
 };
 
 // Arguments of the split pipeline's kernels: the fused kernel's plus the neighbour cache and the work list.
@@ -63,6 +64,9 @@ void lio_launch_split_iteration(const LioSplitParams& S, int n_blocks, hipStream
 void lio_launch_pack_summary(const LioScanState* st, int n_scans, float* out, hipStream_t s);
 void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
                       int* n_active, hipStream_t s);
+void lio_launch_shard_cull(const LioIterParams& P, const float* block_box, int n_blocks, unsigned char* skip, hipStream_t s);
+void lio_launch_block_boxes(const LioBlockDesc* blocks, int n_blocks, const LioScanState* st, const float* sx, const float* sy,
+                            const float* sz, float* box, hipStream_t s);
 void lio_launch_scan_bbox(const void* stage, size_t stride, const LioBlockDesc* prep_blocks, int n_prep_blocks,
                           const LioScanState* st, unsigned* bbox, hipStream_t s);
 void lio_launch_scan_tile_sort(const void* stage, size_t stride, int total_pts,

@@ -464,6 +464,91 @@ __global__ void k_scan_gather_sorted(const unsigned char* __restrict__ stage, si
     x[j] = p[0]; y[j] = p[1]; z[j] = p[2];
 }
 
+// Bounding box (lidar frame, finite coordinates only) of the <= LIO_BLOCK points of every association workgroup, from the
+// tile-sorted SoA: what the map-sharded launch culls workgroups with.  box[(offset + first) / LIO_BLOCK + scan][6].
+__global__ __launch_bounds__(LIO_BLOCK) void k_block_boxes(const LioBlockDesc* __restrict__ blocks, const LioScanState* __restrict__ st,
+                                                           const float* __restrict__ sx, const float* __restrict__ sy,
+                                                           const float* __restrict__ sz, float* __restrict__ box)
+{
+    const LioBlockDesc bd = blocks[blockIdx.x];
+    const int li = bd.first + (int)threadIdx.x;
+    const int base = st[bd.scan].offset;
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    if (li < st[bd.scan].n_pts) {
+        const float v[3] = { sx[base + li], sy[base + li], sz[base + li] };
+#pragma unroll
+        for (int a = 0; a < 3; ++a) if (fabsf(v[a]) <= 3.0e38f) { mn[a] = v[a]; mx[a] = v[a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    }
+    __shared__ float s_mn[LIO_BLOCK / 64][3], s_mx[LIO_BLOCK / 64][3];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float lo = s_mn[0][a], hi = s_mx[0][a];
+        for (int w = 1; w < LIO_BLOCK / 64; ++w) { lo = fminf(lo, s_mn[w][a]); hi = fmaxf(hi, s_mx[w][a]); }
+        float* o = box + (size_t)((base + bd.first) / LIO_BLOCK + bd.scan) * 6;
+        o[a] = lo; o[3 + a] = hi;
+    }
+}
+
+// Map sharding: cull whole workgroups BEFORE the association launch.  One wave per workgroup of the list: the
+// workgroup's points sit in a box (lidar frame, k_block_boxes); its eight corners, transformed, bound every
+// transformed point along the shard axis (an affine image of a box lies inside the hull of the mapped corners).  If
+// that interval -- widened against fp32 rounding -- misses the cells this rank owns, no point of the workgroup can
+// be owned here: this kernel reports the all-zero partial sum and the arrival in the workgroup's place, drops the
+// points' search bounds, and flags the workgroup so that k_s2m_iterate returns at once.  Every other workgroup goes
+// through the exact per-point ownership test of k_s2m_iterate, so the cull can never change a result.
+__global__ __launch_bounds__(256) void k_shard_cull(LioIterParams P, const float* __restrict__ block_box, int n_blocks,
+                                                    unsigned char* __restrict__ skip)
+{
+    const int i = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n_blocks) return;
+    const LioBlockDesc bd = P.blocks[i];
+    const LioScanState* st = &P.state[bd.scan];
+    if (st->done) { if (lane == 0) skip[i] = 0; return; }
+    const int base = st->offset, ax = P.shard.axis;
+    const float* bb = block_box + (size_t)((base + bd.first) / LIO_BLOCK + bd.scan) * 6;
+    const int c = lane & 7;
+    const float bx = (c & 1) ? bb[3] : bb[0], by = (c & 2) ? bb[4] : bb[1], bz = (c & 4) ? bb[5] : bb[2];
+    const float qa = st->T[ax * 4 + 0] * bx + st->T[ax * 4 + 1] * by + st->T[ax * 4 + 2] * bz + st->T[ax * 4 + 3];
+    float lo = qa, hi = qa;
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
+    const float eps = 1.0e-4f + 1.0e-5f * fmaxf(fabsf(lo), fabsf(hi));
+    int c_lo = lio_cell_coord(lo - eps, P.shard.gorigin, P.shard.inv_cell, P.shard.gdim);
+    int c_hi = lio_cell_coord(hi + eps, P.shard.gorigin, P.shard.inv_cell, P.shard.gdim);
+    c_lo = min(max(c_lo, 0), P.shard.gdim - 1);
+    c_hi = min(max(c_hi, 0), P.shard.gdim - 1);
+    // (a workgroup without finite points has an empty box, lo > hi or NaN: never culled, the exact test handles it)
+    const bool culled = (lo <= hi) && (c_hi < P.shard.lo || c_lo >= P.shard.hi);
+    if (lane == 0) skip[i] = culled ? 1 : 0;
+    if (!culled) return;
+    if (P.d5_cache) {                                       // the search bound of a point is only valid from one pass to the very next
+        for (int j = lane; j < LIO_BLOCK; j += 64)
+            if (bd.first + j < st->n_pts) P.d5_cache[base + bd.first + j] = -1.0f;
+    }
+    double* part0 = P.partials + ((size_t)bd.scan * P.max_blk + bd.blk) * LIO_SUMS;
+    if (lane < 28) __hip_atomic_store(part0 + lane, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        const unsigned old = atomicAdd(&P.arrive[bd.scan], 1u);
+        // every workgroup of the scan culled on this rank: its (all-zero) sums are already in sums_out; re-arm the counter
+        if (old == (unsigned)bd.n_blk - 1u) P.arrive[bd.scan] = 0;
+    }
+}
+
 // Start of a registration: transformTobeMapped <- caller's guess, transform and
 // trig for the first pass, counters cleared.  matP / is_degenerate persist
 // (members MO:176-177).  Scans with N_s <= min_scan_pts are skipped (MO:1844).
@@ -557,6 +642,7 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
         const int n8 = gridDim.x >> 3;                     // full groups of 8
         if (wg < n8 * 8) wg = (wg & 7) * n8 + (wg >> 3);
     }
+    if (P.blk_skip != nullptr && P.blk_skip[wg]) return;   // map sharding: k_shard_cull has already reported for this workgroup
     const LioBlockDesc bd = P.blocks[wg];
     LioScanState* st = &P.state[bd.scan];
     if (st->done) return;                                  // workgroup-uniform
@@ -956,6 +1042,19 @@ void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const L
                       int* n_active, hipStream_t s)
 {
     hipLaunchKernelGGL(k_s2m_apply, dim3(n_scans), dim3(64), 0, s, st, n_scans, sums, c, n_active);
+}
+
+void lio_launch_shard_cull(const LioIterParams& P, const float* block_box, int n_blocks, unsigned char* skip, hipStream_t s)
+{
+    if (n_blocks <= 0) return;
+    hipLaunchKernelGGL(k_shard_cull, dim3((n_blocks + 3) / 4), dim3(256), 0, s, P, block_box, n_blocks, skip);
+}
+
+void lio_launch_block_boxes(const LioBlockDesc* blocks, int n_blocks, const LioScanState* st, const float* sx, const float* sy,
+                            const float* sz, float* box, hipStream_t s)
+{
+    if (n_blocks <= 0) return;
+    hipLaunchKernelGGL(k_block_boxes, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, blocks, st, sx, sy, sz, box);
 }
 
 void lio_launch_scan_bbox(const void* stage, size_t stride, const LioBlockDesc* prep_blocks, int n_prep_blocks,

@@ -97,6 +97,9 @@ struct lio_s2m_handle {
     int* d_key_tiles = nullptr; size_t cap_key_tiles = 0;
     int* d_tmp_idx = nullptr; size_t cap_tmp_idx = 0;
     int* d_perm = nullptr; size_t cap_perm = 0;
+    float* d_block_box = nullptr; size_t cap_block_box = 0;   // map sharding: per-workgroup bounding boxes (cull)
+    bool has_block_box = false;
+    unsigned char* d_blk_skip = nullptr; size_t cap_blk_skip = 0;
     int* d_big_list = nullptr; size_t cap_big_list = 0;   // tiles with more than LIO_TILE_CAP points (+ their count in the last slot)
     unsigned* d_scan_bbox = nullptr; size_t cap_scan_bbox = 0;   // [n_scans][6] ordered-uint bounding boxes
     unsigned* h_scan_bbox = nullptr; size_t cap_h_scan_bbox = 0; // pinned mirror
@@ -133,6 +136,9 @@ struct lio_s2m_handle {
     float* d_rec_coeff = nullptr; size_t cap_rec_coeff = 0;
     int* d_rec_nn = nullptr; size_t cap_rec_nn = 0;
 
+    // in-library multi-GPU mode (cfg.n_devices > 1): this handle is only a front; see struct LioMulti
+    struct LioMulti* multi = nullptr;
+
     // resumable launch loop (lio_s2m_batch_run / lio_run_continue)
     bool run_pending = false, run_graph = false, run_has_c = false;
     int run_next = 0, run_units = 0, run_look = 0;
@@ -162,6 +168,47 @@ struct lio_s2m_handle {
     int launches_this_run = 0;
     int* d_active = nullptr;
 };
+
+// ---------------------------------------------------------------- in-library multi-GPU
+// cfg.n_devices > 1: the handle returned by lio_s2m_create is a front for one child handle per entry of
+// cfg.device_ids.  lio_s2m_set_map cuts the map into slabs of 1.001 m cells along its longest axis, balanced by point
+// count; every child holds its slab plus a one-cell halo and processes the scan points whose transformed position falls
+// into a cell it owns (the exact per-point test and the workgroup cull of k_shard_cull).  One host thread drives all
+// devices through their streams; per Gauss-Newton iteration the per-scan sums (32 doubles each) of every child are
+// copied to pinned host memory, added in DEVICE ORDER (bitwise reproducible) and handed back, and every child runs
+// the identical solve -- the join the reference gets from its OpenMP barrier at MO:1622-1686.  The same device may
+// be listed more than once (that is how the mode is tested on a one-GPU box).
+struct LioMulti {
+    std::vector<lio_s2m_handle*> dev;
+    std::vector<double*> d_part, d_tot, h_part;      // per child: device partial / total sums, pinned host partial sums
+    double* h_tot = nullptr;                          // pinned: the sums over all children
+    size_t cap_scans = 0;
+    std::vector<std::vector<int>> shard_idx;          // per child: caller's map index of every point of its shard
+    std::vector<unsigned char> gather;                // host staging of one shard's records
+    int n_scans = 0;
+};
+
+static int lio_multi_reserve(lio_s2m_handle* h, size_t n_scans)
+{
+    LioMulti* m = h->multi;
+    if (n_scans <= m->cap_scans) return LIO_OK;
+    const size_t cap = n_scans + n_scans / 4 + 16, bytes = cap * LIO_SUMS * sizeof(double);
+    for (size_t c = 0; c < m->dev.size(); ++c) {
+        HIPCHK(hipSetDevice(m->dev[c]->cfg.device_id));
+        if (m->d_part[c]) HIPCHK(hipFree(m->d_part[c]));
+        if (m->d_tot[c]) HIPCHK(hipFree(m->d_tot[c]));
+        if (m->h_part[c]) HIPCHK(hipHostFree(m->h_part[c]));
+        m->d_part[c] = m->d_tot[c] = m->h_part[c] = nullptr;
+        HIPCHK(hipMalloc((void**)&m->d_part[c], bytes));
+        HIPCHK(hipMalloc((void**)&m->d_tot[c], bytes));
+        HIPCHK(hipHostMalloc((void**)&m->h_part[c], bytes, hipHostMallocPortable));
+    }
+    if (m->h_tot) HIPCHK(hipHostFree(m->h_tot));
+    m->h_tot = nullptr;
+    HIPCHK(hipHostMalloc((void**)&m->h_tot, bytes, hipHostMallocPortable));
+    m->cap_scans = cap;
+    return LIO_OK;
+}
 
 extern "C" int lio_version(void) { return LIO_VERSION; }
 extern "C" const char* lio_last_error(void) { return g_last_error.c_str(); }
@@ -200,6 +247,8 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->sort_scan = 1;
     c->nn_cache = 1;
     c->pipeline = 0;
+    c->n_devices = 1;
+    for (int i = 0; i < 8; ++i) c->device_ids[i] = i;
 }
 
 static void lio_fill_consts(lio_s2m_handle* h)
@@ -240,6 +289,33 @@ extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return lio_fail(LIO_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return lio_fail(LIO_ERR_ARG, "device_id out of range");
+    if (cfg->n_devices > 1) {
+        // in-library multi-GPU: a front handle + one child per listed device (see struct LioMulti)
+        if (cfg->n_devices > 8) return lio_fail(LIO_ERR_ARG, "n_devices must be <= 8");
+        for (int i = 0; i < cfg->n_devices; ++i)
+            if (cfg->device_ids[i] < 0 || cfg->device_ids[i] >= ndev) return lio_fail(LIO_ERR_ARG, "device_ids entry out of range");
+        if (cfg->use_lds || cfg->pipeline == 2 || cfg->kernel_variant > 1)
+            return lio_fail(LIO_ERR_ARG, "the multi-device mode runs the default kernel only");
+        lio_s2m_handle* f = new lio_s2m_handle();
+        f->cfg = *cfg;
+        lio_fill_consts(f);
+        f->shard.axis = -1;
+        f->multi = new LioMulti();
+        for (int i = 0; i < cfg->n_devices; ++i) {
+            lio_s2m_config cc = *cfg;
+            cc.n_devices = 1;
+            cc.device_id = cfg->device_ids[i];
+            cc.use_graph = 0;                        // the loop is driven iteration by iteration (one exchange each)
+            lio_s2m_handle* ch = nullptr;
+            const int rc = lio_s2m_create(&cc, &ch);
+            if (rc != LIO_OK) { lio_s2m_destroy(f); return rc; }
+            f->multi->dev.push_back(ch);
+            f->multi->d_part.push_back(nullptr); f->multi->d_tot.push_back(nullptr); f->multi->h_part.push_back(nullptr);
+        }
+        f->multi->shard_idx.resize((size_t)cfg->n_devices);
+        *out = f;
+        return LIO_OK;
+    }
     HIPCHK(hipSetDevice(cfg->device_id));
     lio_s2m_handle* h = new lio_s2m_handle();
     h->cfg = *cfg;
@@ -258,6 +334,21 @@ extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
 extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
 {
     if (!h) return;
+    if (h->multi) {
+        LioMulti* m = h->multi;
+        for (size_t c = 0; c < m->dev.size(); ++c) {
+            (void)hipSetDevice(m->dev[c]->cfg.device_id);
+            (void)hipStreamSynchronize(m->dev[c]->stream);
+            if (m->d_part[c]) (void)hipFree(m->d_part[c]);
+            if (m->d_tot[c]) (void)hipFree(m->d_tot[c]);
+            if (m->h_part[c]) (void)hipHostFree(m->h_part[c]);
+            lio_s2m_destroy(m->dev[c]);
+        }
+        if (m->h_tot) (void)hipHostFree(m->h_tot);
+        delete m;
+        delete h;
+        return;
+    }
     (void)hipSetDevice(h->cfg.device_id);
     (void)hipStreamSynchronize(h->stream);
     if (h->corner) { lio_s2m_destroy(h->corner); h->corner = nullptr; }
@@ -267,7 +358,7 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
                      h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
                      h->d_nn_cache, h->d_summary, h->d_groups, h->d_cache_idx, h->d_cache_q, h->d_pt_flag,
-                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox };
+                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox, h->d_block_box, h->d_blk_skip };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < LIO_MAX_ITERS; ++i) {               // (a handle whose creation failed half-way holds nulls)
         if (h->ev_beg[i]) (void)hipEventDestroy(h->ev_beg[i]);
@@ -287,6 +378,7 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
 
 extern "C" int lio_s2m_set_stream(lio_s2m_handle* h, void* hip_stream)
 {
+    if (h && h->multi) return lio_fail(LIO_ERR_ARG, "not available on a multi-device handle (cfg.n_devices > 1 shards inside the library)");
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->own_stream && h->stream) HIPCHK(hipStreamDestroy(h->stream));
@@ -388,11 +480,83 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
     return LIO_OK;
 }
 
+// Multi-device set_map: slab plan on the host (the same arithmetic as lio-slam_amd/multigpu.py plan_shards and as the
+// device-side owner test), then every child receives its slab + one-cell halo in the caller's record layout.
+static int lio_multi_set_map(lio_s2m_handle* h, const void* pts, size_t n, size_t stride)
+{
+    LioMulti* m = h->multi;
+    const int world = (int)m->dev.size();
+    const unsigned char* src = (const unsigned char*)pts;
+    const float cell = h->cfg.cell_size > 0.0f ? h->cfg.cell_size : sqrtf(h->cfg.max_sq_dist) * 1.001f;
+    const float inv_cell = 1.0f / cell;
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (size_t i = 0; i < n; ++i) {
+        const float* p = (const float*)(src + i * stride);
+        for (int a = 0; a < 3; ++a)
+            if (fabsf(p[a]) <= 1.0e15f) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
+    }
+    float origin[3];
+    int32_t dims[3];
+    int axis = 0;
+    for (int a = 0; a < 3; ++a) {
+        if (!(mn[a] <= mx[a])) { mn[a] = 0.0f; mx[a] = 0.0f; }
+        origin[a] = mn[a] - 0.5f * cell;
+        dims[a] = (int32_t)floor(((double)mx[a] - origin[a]) * inv_cell) + 2;
+        if (dims[a] > dims[axis]) axis = a;
+    }
+    auto cell_of = [&](float v) {                          // lio_cell_coord(), clamped to the grid
+        float c = floorf((v - origin[axis]) * inv_cell);
+        c = fminf(fmaxf(c, -4.0f), (float)(dims[axis] + 3));
+        int ci = (int)c;
+        return ci < 0 ? 0 : (ci > dims[axis] - 1 ? dims[axis] - 1 : ci);
+    };
+    std::vector<long long> cum((size_t)dims[axis], 0);
+    std::vector<int> pc(n);
+    for (size_t i = 0; i < n; ++i) {
+        const float* p = (const float*)(src + i * stride);
+        const bool ok = fabsf(p[0]) <= 1.0e15f && fabsf(p[1]) <= 1.0e15f && fabsf(p[2]) <= 1.0e15f;
+        pc[i] = ok ? cell_of(p[axis]) : -1000;             // non-finite points belong to no slab (they are no neighbour of anything)
+        if (ok) cum[(size_t)pc[i]]++;
+    }
+    for (size_t c = 1; c < cum.size(); ++c) cum[c] += cum[c - 1];
+    const long long total = cum.empty() ? 0 : cum.back();
+    std::vector<int> bounds((size_t)world + 1, 0);
+    bounds[(size_t)world] = dims[axis];
+    for (int r = 1; r < world; ++r) {
+        const double want = (double)total * r / world;
+        size_t lo = 0;
+        while (lo < cum.size() && (double)cum[lo] < want) ++lo;   // first cell whose cumulative count reaches the share
+        bounds[(size_t)r] = (int)lo + 1;
+        if (bounds[(size_t)r] > dims[axis]) bounds[(size_t)r] = dims[axis];
+        if (bounds[(size_t)r] < bounds[(size_t)r - 1]) bounds[(size_t)r] = bounds[(size_t)r - 1];
+    }
+    for (int r = 0; r < world; ++r) {
+        const int lo = bounds[(size_t)r], hi = bounds[(size_t)r + 1];
+        std::vector<int>& idx = m->shard_idx[(size_t)r];
+        idx.clear();
+        for (size_t i = 0; i < n; ++i)
+            if (pc[i] >= lo - 1 && pc[i] < hi + 1) idx.push_back((int)i);
+        m->gather.resize((idx.size() ? idx.size() : 1) * stride);
+        for (size_t k = 0; k < idx.size(); ++k) memcpy(m->gather.data() + k * stride, src + (size_t)idx[k] * stride, stride);
+        lio_s2m_handle* ch = m->dev[(size_t)r];
+        int rc = lio_s2m_set_map(ch, m->gather.data(), idx.size(), stride);
+        if (rc == LIO_OK) rc = lio_s2m_set_global_grid(ch, origin, dims);
+        if (rc == LIO_OK) rc = lio_s2m_set_shard(ch, axis, lo, hi);
+        if (rc != LIO_OK) return rc;
+    }
+    h->has_map = true;
+    h->n_map = n;
+    h->prof = m->dev[0]->prof;
+    h->prof.n_map = (int64_t)n;
+    return LIO_OK;
+}
+
 extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, size_t stride)
 {
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     if (n > 0 && !pts) return lio_fail(LIO_ERR_ARG, "null map pointer");
     if (stride < 12 || (stride & 3)) return lio_fail(LIO_ERR_ARG, "stride_bytes must be >= 12 and a multiple of 4");
+    if (h->multi) return lio_multi_set_map(h, pts, n, stride);
     if (n >= (1ull << 25)) return lio_fail(LIO_ERR_CAPACITY, "map too large ((2k+1)^2 x n records must fit a 31-bit offset)");
     if (h->map_src) return lio_fail(LIO_ERR_ARG, "this handle searches another handle's map (lio_s2m_share_map)");
     HIPCHK(hipSetDevice(h->cfg.device_id));
@@ -435,6 +599,7 @@ extern "C" int lio_s2m_set_global_grid(lio_s2m_handle* h, const float origin[3],
 
 extern "C" int lio_s2m_set_scan_shard(lio_s2m_handle* h, int32_t rank, int32_t world)
 {
+    if (h && h->multi) return lio_fail(LIO_ERR_ARG, "not available on a multi-device handle (cfg.n_devices > 1 shards inside the library)");
     if (!h || world < 1 || rank < 0 || rank >= world) return lio_fail(LIO_ERR_ARG, "need 0 <= rank < world");
     h->block_rank = rank;
     h->block_world = world;
@@ -447,6 +612,7 @@ extern "C" int lio_s2m_set_scan_shard(lio_s2m_handle* h, int32_t rank, int32_t w
 extern "C" int lio_s2m_share_map(lio_s2m_handle* h, lio_s2m_handle* map_owner)
 {
     if (!h || h == map_owner) return lio_fail(LIO_ERR_ARG, "need two different handles");
+    if (h->multi || (map_owner && map_owner->multi)) return lio_fail(LIO_ERR_ARG, "not available on a multi-device handle");
     if (map_owner && (map_owner->map_src || map_owner->cfg.device_id != h->cfg.device_id))
         return lio_fail(LIO_ERR_ARG, "the map owner must hold its own map on the same device");
     h->map_src = map_owner;
@@ -489,6 +655,7 @@ extern "C" int lio_s2m_batch_upload_async(lio_s2m_handle* h, int32_t n_scans, co
 
 extern "C" int lio_s2m_set_shard(lio_s2m_handle* h, int32_t axis, int32_t lo, int32_t hi)
 {
+    if (h && h->multi) return lio_fail(LIO_ERR_ARG, "not available on a multi-device handle (cfg.n_devices > 1 shards inside the library)");
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     if (axis < 0) { h->shard.axis = -1; return LIO_OK; }
     if (axis > 2 || !h->has_global) return lio_fail(LIO_ERR_ARG, "set_global_grid first; axis in 0..2");
@@ -540,6 +707,21 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     if (!h || !scans || !n_pts) return lio_fail(LIO_ERR_ARG, "null argument");
     if (n_scans < 1) return lio_fail(LIO_ERR_ARG, "n_scans must be >= 1");
     if (stride < 12 || (stride & 3)) return lio_fail(LIO_ERR_ARG, "stride_bytes must be >= 12 and a multiple of 4");
+    if (h->multi) {
+        // every device holds every scan: which device owns a point follows the pose, iteration by iteration
+        for (lio_s2m_handle* ch : h->multi->dev) {
+            ch->defer_sync = true;                       // all copies in flight together, one wait per device below
+            ch->xyz_off = h->xyz_off;
+            const int rc = lio_s2m_batch_upload(ch, n_scans, scans, n_pts, stride);
+            ch->defer_sync = false;
+            if (rc != LIO_OK) return rc;
+        }
+        h->xyz_off = 0;
+        for (lio_s2m_handle* ch : h->multi->dev) { const int rc = lio_s2m_batch_sync(ch); if (rc != LIO_OK) return rc; }
+        h->multi->n_scans = n_scans;
+        h->n_scans = n_scans;
+        return lio_multi_reserve(h, (size_t)n_scans);
+    }
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     size_t total = 0, max_n = 0;
@@ -741,6 +923,14 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     }
     if (total && !h->sorted)
         lio_launch_aos_to_soa(stage, stride, (int)total, h->d_sx, h->d_sy, h->d_sz, nullptr, h->stream);
+    h->has_block_box = false;
+    if (h->shard.axis >= 0 && ppt == 1 && !blocks.empty()) {
+        // map sharding: the box of every workgroup's points, for the cull at the head of k_s2m_iterate
+        HIPCHK(lio_grow(&h->d_block_box, &h->cap_block_box, (tt / LIO_BLOCK + (size_t)n_scans + 2) * 6));
+        HIPCHK(lio_grow(&h->d_blk_skip, &h->cap_blk_skip, blocks.size()));
+        lio_launch_block_boxes(h->d_blocks, (int)blocks.size(), h->d_state, h->d_sx, h->d_sy, h->d_sz, h->d_block_box, h->stream);
+        h->has_block_box = true;
+    }
     HIPCHK(hipMemsetAsync(h->d_arrive, 0, (size_t)n_scans * sizeof(unsigned), h->stream));
     if (!h->defer_sync) HIPCHK(hipStreamSynchronize(h->stream));   // the caller's scans are borrowed only for this call
     HIPCHK(hipGetLastError());
@@ -755,6 +945,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
 extern "C" int lio_s2m_set_corner_map(lio_s2m_handle* h, const void* pts, size_t n, size_t stride)
 {
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    if (h->multi) return lio_fail(LIO_ERR_ARG, "the corner extension is not available on a multi-device handle");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();
     if (!h->corner) {
@@ -836,6 +1027,11 @@ extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
 {
     if (!h || !poses) return lio_fail(LIO_ERR_ARG, "null argument");
     if (h->n_scans < 1) return lio_fail(LIO_ERR_ARG, "no batch uploaded");
+    if (h->multi) {
+        for (lio_s2m_handle* ch : h->multi->dev) { const int rc = lio_s2m_batch_set_poses(ch, poses); if (rc != LIO_OK) return rc; }
+        h->poses_set = true;
+        return LIO_OK;
+    }
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     h->run_pending = false;            // (a run whose results were never fetched is abandoned)
@@ -878,6 +1074,10 @@ extern "C" int lio_s2m_set_degeneracy(lio_s2m_handle* h, int32_t scan, const flo
 {
     if (!h || !matP) return lio_fail(LIO_ERR_ARG, "null argument");
     if (scan < 0 || scan >= h->n_scans) return lio_fail(LIO_ERR_ARG, "scan slot out of range");
+    if (h->multi) {
+        for (lio_s2m_handle* ch : h->multi->dev) { const int rc = lio_s2m_set_degeneracy(ch, scan, matP, is_degenerate); if (rc != LIO_OK) return rc; }
+        return LIO_OK;
+    }
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     LioScanState& st = h->h_state[scan];
@@ -917,6 +1117,7 @@ static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_ou
     P.rec_nn = rec ? h->d_rec_nn : nullptr;
     P.stamps = (h->cfg.profile == 2) ? h->d_stamps : nullptr;
     P.d5_cache = (h->cfg.nn_cache && !h->cfg.use_lds) ? h->d_nn_cache : nullptr;
+    P.blk_skip = (h->shard.axis >= 0 && h->has_block_box && sums_out != nullptr && !h->cfg.use_lds && h->ppt == 1) ? h->d_blk_skip : nullptr;
 }
 
 static void lio_fill_split(lio_s2m_handle* h, const LioIterParams& P, LioSplitParams& S)
@@ -967,6 +1168,7 @@ static void lio_launch_gn(lio_s2m_handle* h, const LioIterParams& P, const LioIt
 
 extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
 {
+    if (h && h->multi) return lio_fail(LIO_ERR_ARG, "not available on a multi-device handle (cfg.n_devices > 1 shards inside the library)");
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     if (!lio_map_of(h)->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
     if (h->n_scans < 1 || !h->poses_set) return lio_fail(LIO_ERR_ARG, "batch_upload and batch_set_poses first");
@@ -1063,8 +1265,48 @@ static int lio_run_continue(lio_s2m_handle* h, bool blocking)
     return LIO_OK;
 }
 
+// Multi-device Gauss-Newton loop (blocking): association on every device, exchange of the per-scan sums through pinned
+// host memory (added in device order), the identical solve on every device; MO:1848-1859 with the join of MO:1622-1686.
+static int lio_multi_run(lio_s2m_handle* h)
+{
+    LioMulti* m = h->multi;
+    if (!h->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
+    if (m->n_scans < 1 || !h->poses_set) return lio_fail(LIO_ERR_ARG, "batch_upload and batch_set_poses first");
+    const size_t n_val = (size_t)m->n_scans * LIO_SUMS, bytes = n_val * sizeof(double);
+    for (lio_s2m_handle* ch : m->dev) { const int rc = lio_s2m_batch_begin(ch); if (rc != LIO_OK) return rc; }
+    for (int it = 0; it < h->cfg.max_iters; ++it) {                         // MO:1848
+        for (size_t c = 0; c < m->dev.size(); ++c) {
+            lio_s2m_handle* ch = m->dev[c];
+            const int rc = lio_s2m_batch_iter_partial(ch, m->d_part[c]);
+            if (rc != LIO_OK) return rc;
+            HIPCHK(hipMemcpyAsync(m->h_part[c], m->d_part[c], bytes, hipMemcpyDeviceToHost, ch->stream));
+        }
+        for (lio_s2m_handle* ch : m->dev) { HIPCHK(hipSetDevice(ch->cfg.device_id)); HIPCHK(hipStreamSynchronize(ch->stream)); }
+        for (size_t k = 0; k < n_val; ++k) {                                // fixed order: bitwise reproducible
+            double v = m->h_part[0][k];
+            for (size_t c = 1; c < m->dev.size(); ++c) v += m->h_part[c][k];
+            m->h_tot[k] = v;
+        }
+        for (size_t c = 0; c < m->dev.size(); ++c) {
+            lio_s2m_handle* ch = m->dev[c];
+            HIPCHK(hipSetDevice(ch->cfg.device_id));
+            HIPCHK(hipMemcpyAsync(m->d_tot[c], m->h_tot, bytes, hipMemcpyHostToDevice, ch->stream));
+            const int rc = lio_s2m_batch_iter_apply(ch, m->d_tot[c]);
+            if (rc != LIO_OK) return rc;
+        }
+        int32_t active = 0;
+        const int rc = lio_s2m_batch_poll_active(m->dev[0], it, &active);   // every device solves the same sums
+        if (rc != LIO_OK) return rc;
+        if (active == 0) break;                                             // MO:1857-1858 for every scan
+    }
+    for (lio_s2m_handle* ch : m->dev) { const int rc = lio_s2m_batch_sync(ch); if (rc != LIO_OK) return rc; }
+    h->ran = true;
+    return LIO_OK;
+}
+
 extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
 {
+    if (h && h->multi) return lio_multi_run(h);
     int rc = lio_s2m_batch_begin(h);
     if (rc != LIO_OK) return rc;
     LioIterParams& P = h->run_P;
@@ -1111,6 +1353,8 @@ extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
     LioIterParams Pcs;
     const bool with_corners = h->corner_active && h->corner->n_blocks > 0;
     if (with_corners) lio_fill_params_corner(h, Pcs, d_sums);
+    if (P.blk_skip && !h->split) lio_launch_shard_cull(P, h->d_block_box, h->n_blocks, h->d_blk_skip, h->stream);
+    else P.blk_skip = nullptr;
     lio_launch_gn(h, P, with_corners ? &Pcs : nullptr);
     if (prof) HIPCHK(hipEventRecord(h->ev_end[it], h->stream));
     h->launches_this_run++;
@@ -1160,6 +1404,10 @@ extern "C" int lio_s2m_batch_n_active(lio_s2m_handle* h, int32_t* n_active)
 extern "C" int lio_s2m_batch_sync(lio_s2m_handle* h)
 {
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    if (h->multi) {
+        for (lio_s2m_handle* ch : h->multi->dev) { const int rc = lio_s2m_batch_sync(ch); if (rc != LIO_OK) return rc; }
+        return LIO_OK;
+    }
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     { const int rcc = lio_run_continue(h, true); if (rcc != LIO_OK) return rcc; }
@@ -1171,6 +1419,16 @@ extern "C" int lio_s2m_batch_sync(lio_s2m_handle* h)
 extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_result* results)
 {
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    if (h->multi) {
+        if (!h->ran) return lio_fail(LIO_ERR_ARG, "nothing has been run");
+        // every device holds the same per-scan state; the others are read as well so that their host mirrors
+        // (persistent matP / isDegenerate, MO:176-177) stay current
+        int rc = LIO_OK;
+        for (size_t c = h->multi->dev.size(); c-- > 0 && rc == LIO_OK;)
+            rc = lio_s2m_batch_results(h->multi->dev[c], c == 0 ? poses : nullptr, c == 0 ? results : nullptr);
+        h->prof = h->multi->dev[0]->prof;
+        return rc;
+    }
     if (!h->ran) return lio_fail(LIO_ERR_ARG, "nothing has been run");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
@@ -1350,6 +1608,30 @@ extern "C" int lio_s2m_get_correspondences(lio_s2m_handle* h, int32_t scan, uint
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     if (h->cfg.record_corr_iter < 0) return lio_fail(LIO_ERR_ARG, "record_corr_iter was not set at create time");
     if (scan < 0 || scan >= h->n_scans) return lio_fail(LIO_ERR_ARG, "scan slot out of range");
+    if (h->multi) {
+        // a point's record lives on the device that owned it in that iteration; neighbour indices come back in the
+        // caller's map order (a shard numbers its points locally)
+        LioMulti* m = h->multi;
+        const size_t n = (size_t)m->dev[0]->h_state[scan].n_pts;
+        std::vector<uint8_t> f(n);
+        std::vector<float> cf(n * 4);
+        std::vector<int32_t> nn(n * 5);
+        if (flag) memset(flag, 0, n);
+        if (coeff4) memset(coeff4, 0, n * 4 * sizeof(float));
+        if (nn_idx5) for (size_t i = 0; i < n * 5; ++i) nn_idx5[i] = -1;
+        for (size_t c = 0; c < m->dev.size(); ++c) {
+            const int rc = lio_s2m_get_correspondences(m->dev[c], scan, f.data(), cf.data(), nn.data());
+            if (rc != LIO_OK) return rc;
+            const std::vector<int>& idx = m->shard_idx[c];
+            for (size_t i = 0; i < n; ++i) {
+                if (nn[i * 5] < 0) continue;                                // not processed (not owned / gate failed) on this device
+                if (flag) flag[i] = f[i];
+                if (coeff4) memcpy(coeff4 + i * 4, cf.data() + i * 4, 4 * sizeof(float));
+                if (nn_idx5) for (int j = 0; j < 5; ++j) nn_idx5[i * 5 + j] = idx[(size_t)nn[i * 5 + j]];
+            }
+        }
+        return LIO_OK;
+    }
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     const size_t off = (size_t)h->h_state[scan].offset, n = (size_t)h->h_state[scan].n_pts;
@@ -1364,6 +1646,7 @@ extern "C" int lio_s2m_get_correspondences(lio_s2m_handle* h, int32_t scan, uint
 extern "C" int lio_s2m_get_profile(lio_s2m_handle* h, lio_s2m_profile* out)
 {
     if (!h || !out) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (h->multi) h->prof.n_map = (int64_t)h->n_map;
     *out = h->prof;
     return LIO_OK;
 }

@@ -108,7 +108,12 @@ class ShardedRunner:
         self.handles = []
         map_xyz = np.ascontiguousarray(map_xyz, np.float32)
         if mode == "map":
-            self.plan = plan_shards(map_xyz, world)
+            # the slab plan must use the cell the device-side owner test uses (lio_s2m_set_shard: cfg.cell_size, or
+            # sqrt(max_sq_dist) * 1.001): a one-cell halo only guarantees exact 5-NN sets for cells of at least the gate radius
+            cell = np.float32(cfg.get("cell_size") or 0.0)
+            if not cell > 0:
+                cell = default_cell(cfg.get("max_sq_dist", 1.0))
+            self.plan = plan_shards(map_xyz, world, cell=cell)
             self.idx = shard_points(map_xyz, self.plan, rank)
         else:
             self.idx = np.arange(len(map_xyz))
