@@ -302,7 +302,11 @@ def main():
         # iteration just enqueued would drain the GPU once per iteration and sub-batch)
         kcfg_sh = dict(kcfg)
         kcfg_sh.pop("lookahead")
-        runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2,
+        # slabs balanced by where the REGISTERED points will fall (a sample of batch 0 at its initial poses), not by where
+        # the map points are: scan returns are dense around the sensor, the map is not
+        load = np.concatenate([multi.transform_f32(synth.pose_matrix(poses0[i])[:3].astype(np.float32).reshape(12), scans[i][::16])
+                               for i in range(0, B, 4)])
+        runner = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode=args.shard, groups=2, load_xyz=load,
                                      lookahead=max(args.lookahead, int(os.environ.get("BENCH_SHARD_LAG", "2"))), **kcfg_sh)
         handles = [runner.handles[0]]
         prof0 = handles[0].profile()

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_scan_tile_keys(const unsigned char* __r
         const int tx = lio_tile_coord(p[0], t.ox, t.inv_tile, t.ntx);
         const int ty = lio_tile_coord(p[1], t.oy, t.inv_tile, t.nty);
         const int tz = lio_tile_coord(p[2], t.oz, t.inv_tile, t.ntz);
-        key = t.key_offset + (tz * t.nty + ty) * t.ntx + tx;
+        key = t.key_offset + tx * t.mx + ty * t.my + tz * t.mz;
         key_of[gi] = key;
     }
     lio_wave_key_add<false>(key_count, key, valid);

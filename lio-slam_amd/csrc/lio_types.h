@@ -88,4 +88,6 @@ struct LioScanTiles {
     float inv_tile;
     int32_t ntx, nty, ntz;
     int32_t key_offset;      // first tile key of this scan in the batch-wide key space
+    int32_t mx, my, mz;      // key = key_offset + tx*mx + ty*my + tz*mz: x-fastest by default; with a sharded map the shard
+                             // axis is the SLOWEST one, so that a workgroup's points form a thin slice across that axis
 };

@@ -901,6 +901,13 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
             }
             t.ox = mn[0]; t.oy = mn[1]; t.oz = mn[2];
             t.key_offset = (int)n_keys;
+            // Order of the tiles = order of the association workgroups' points.  Unsharded: x fastest.  With a sharded map
+            // the shard axis varies slowest, so a workgroup's 256 points form a slice about one tile thick ACROSS that
+            // axis and k_shard_cull can drop it on every rank but one or two.  (Lidar frame; effective while the
+            // vehicle's heading stays within ~45 degrees of a map axis, merely less effective -- never wrong -- otherwise.)
+            t.mx = 1; t.my = t.ntx; t.mz = t.ntx * t.nty;
+            if (h->shard.axis == 0) { t.mz = 1; t.my = t.ntz; t.mx = t.ntz * t.nty; }
+            else if (h->shard.axis == 1) { t.mx = 1; t.mz = t.ntx; t.my = t.ntx * t.ntz; }
             tiles[s] = t;
             n_keys += (long long)t.ntx * t.nty * t.ntz;
         }
@@ -1353,8 +1360,19 @@ extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
     LioIterParams Pcs;
     const bool with_corners = h->corner_active && h->corner->n_blocks > 0;
     if (with_corners) lio_fill_params_corner(h, Pcs, d_sums);
-    if (P.blk_skip && !h->split) lio_launch_shard_cull(P, h->d_block_box, h->n_blocks, h->d_blk_skip, h->stream);
-    else P.blk_skip = nullptr;
+    if (P.blk_skip && !h->split && !getenv("LIO_NO_CULL")) {
+        lio_launch_shard_cull(P, h->d_block_box, h->n_blocks, h->d_blk_skip, h->stream);
+        if (getenv("LIO_CULL_STATS")) {                  // diagnostics only (synchronises)
+            std::vector<unsigned char> sk((size_t)h->n_blocks);
+            HIPCHK(hipMemcpyAsync(sk.data(), h->d_blk_skip, sk.size(), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            size_t c = 0;
+            for (unsigned char v : sk) c += v;
+            fprintf(stderr, "[liogpu] shard cull: %zu of %d workgroups culled (iteration %d)\n", c, h->n_blocks, it);
+        }
+    } else {
+        P.blk_skip = nullptr;
+    }
     lio_launch_gn(h, P, with_corners ? &Pcs : nullptr);
     if (prof) HIPCHK(hipEventRecord(h->ev_end[it], h->stream));
     h->launches_this_run++;

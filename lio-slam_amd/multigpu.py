@@ -30,11 +30,14 @@ def cell_coord(v, origin, inv_cell, n):
     return c.astype(np.int64)
 
 
-def plan_shards(map_xyz, world, cell=None):
+def plan_shards(map_xyz, world, cell=None, load_xyz=None):
     """Global grid + slab boundaries.  Deterministic, identical on every rank.
 
     Returns dict(origin f32[3], dims int[3], cell, inv_cell, axis, bounds int[world+1]);
     rank r owns global cells [bounds[r], bounds[r+1]) along `axis`.
+    load_xyz: optional world-frame sample of the points that will be REGISTERED (scan points at their initial poses).
+    A rank's work is the scan points that fall into its slab, not the map points it stores; with a sample the slabs
+    are balanced by it (scan returns are dense around the sensor, the map is not).  Any bounds give the same results.
     """
     map_xyz = np.asarray(map_xyz, np.float32)
     cell = np.float32(cell if cell is not None else default_cell())
@@ -47,7 +50,8 @@ def plan_shards(map_xyz, world, cell=None):
     origin = (mn - np.float32(0.5) * cell).astype(np.float32)
     dims = (np.floor((mx.astype(np.float64) - origin) * inv_cell) + 2).astype(np.int64)
     axis = int(np.argmax(dims))
-    c = np.clip(cell_coord(map_xyz[:, axis], origin[axis], inv_cell, dims[axis]), 0, dims[axis] - 1)
+    src = map_xyz if load_xyz is None or len(load_xyz) == 0 else np.asarray(load_xyz, np.float32)
+    c = np.clip(cell_coord(src[:, axis], origin[axis], inv_cell, dims[axis]), 0, dims[axis] - 1)
     hist = np.bincount(c, minlength=int(dims[axis]))
     cum = np.cumsum(hist)
     total = cum[-1]
@@ -102,7 +106,7 @@ class ShardedRunner:
     """
 
     def __init__(self, pkg, map_xyz, rank, world, dist, torch, mode="map", groups=2, deterministic=False,
-                 lookahead=2, **cfg):
+                 lookahead=2, load_xyz=None, **cfg):
         self.rank, self.world, self.dist, self.torch = rank, world, dist, torch
         self.mode, self.deterministic, self.lookahead = mode, deterministic, lookahead
         self.handles = []
@@ -113,7 +117,7 @@ class ShardedRunner:
             cell = np.float32(cfg.get("cell_size") or 0.0)
             if not cell > 0:
                 cell = default_cell(cfg.get("max_sq_dist", 1.0))
-            self.plan = plan_shards(map_xyz, world, cell=cell)
+            self.plan = plan_shards(map_xyz, world, cell=cell, load_xyz=load_xyz)
             self.idx = shard_points(map_xyz, self.plan, rank)
         else:
             self.idx = np.arange(len(map_xyz))

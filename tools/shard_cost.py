@@ -16,10 +16,13 @@ scans1 = [np.ascontiguousarray(cat[offs[i]:offs[i + 1]]) for i in range(len(lens
 map_xyz, poses1 = z["map"], z["poses0"][:512]
 
 
-def one(mode, world, rank):
+def one(mode, world, rank, balance="load"):
     s2m = pkg.ScanToMap(profile=1, max_iters=2)
     if mode == "map":
-        plan = mg.plan_shards(map_xyz, world)
+        synth = importlib.import_module("lio-slam_amd.synth")
+        load = np.concatenate([mg.transform_f32(synth.pose_matrix(poses1[i])[:3].astype(np.float32).reshape(12), scans1[i][::16])
+                               for i in range(0, len(scans1), 4)]) if balance == "load" else None
+        plan = mg.plan_shards(map_xyz, world, load_xyz=load)
         idx = mg.shard_points(map_xyz, plan, rank)
         s2m.set_map(np.ascontiguousarray(map_xyz[idx]))
         s2m.set_global_grid([float(v) for v in plan["origin"]], [int(v) for v in plan["dims"]])
@@ -43,7 +46,7 @@ def one(mode, world, rank):
 
 base = one("scan", 1, 0)
 print(f"N=1: {base:.3f} ms per launch (512 scans)")
-for mode in ("map", "scan"):
+for mode in ("map", "map/map-point-balanced", "scan"):
     for world in (2, 4, 8):
-        t = [one(mode, world, r) for r in sorted({0, world // 2, world - 1})]
-        print(f"{mode:4s} N={world}: slowest sampled rank {max(t):.3f} ms for {512 * world} scans -> kernel-only weak-scaling efficiency {base / max(t):.2f}")
+        t = [one(mode.split("/")[0], world, r, "map" if "/" in mode else "load") for r in range(world)]
+        print(f"{mode:4s} N={world}: slowest rank {max(t):.3f} ms for {512 * world} scans -> kernel-only weak-scaling efficiency {base / max(t):.2f}")
