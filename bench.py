@@ -351,6 +351,11 @@ def main():
                     nb_ = (b + 1) % NB
                     handles[(k + 1) % nh].batch_upload_raw(ptr(nb_), batch_npts[nb_], stride)
                 out = h.batch_results(with_results=False)[0]
+                if keep is not None:                      # launch accounting of EVERY timed step (HIP events on h's stream)
+                    pr = h.profile()
+                    keep.setdefault("unit_ms", []).extend(pr.launch_ms[:pr.n_units])
+                    keep["launches"] = keep.get("launches", 0) + pr.n_units * max(pr.unit_iters, 1)
+                    keep["point_iters"] = keep.get("point_iters", 0) + int(pr.point_iters)
                 if nh == 1 and k + 1 < n_steps:
                     nb_ = (b + 1) % NB
                     h.batch_upload_raw(ptr(nb_), batch_npts[nb_], stride)
@@ -361,6 +366,8 @@ def main():
     keep = {}
     run_stream(args.warmup, dev_rec, keep=keep)
     sync_all()
+    for k_ in ("unit_ms", "launches", "point_iters"):      # (accounting restarts with the timed region)
+        keep.pop(k_, None)
     t0 = time.perf_counter()
     run_stream(args.steps, dev_rec, first_batch=args.warmup, keep=keep)
     sync_all()
@@ -400,9 +407,16 @@ def main():
         lms = np.repeat(unit_ms / ui, ui)
         pts_per_launch = np.array([int(ns_last[iters > i].sum()) for i in range(n_launch)], dtype=np.float64)
     live = lms > 0
-    bytes_per_launch = BYTES_PER_POINT_ITER * pts_per_launch[live].mean() if live.any() else 0.0
-    ms_per_launch = float(lms[live].mean()) if live.any() else float("nan")
-    achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if live.any() else 0.0
+    if runner is None and keep.get("launches"):
+        # single GPU: averages over ALL launches of ALL timed steps (what rocprofv3's kernel statistics average too)
+        tot_ms = float(np.sum(keep["unit_ms"]))
+        ms_per_launch = tot_ms / keep["launches"]
+        bytes_per_launch = BYTES_PER_POINT_ITER * keep["point_iters"] / keep["launches"]
+        achieved = BYTES_PER_POINT_ITER * keep["point_iters"] / (tot_ms * 1e-3) / 1e9
+    else:
+        bytes_per_launch = BYTES_PER_POINT_ITER * pts_per_launch[live].mean() if live.any() else 0.0
+        ms_per_launch = float(lms[live].mean()) if live.any() else float("nan")
+        achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if live.any() else 0.0
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
@@ -442,9 +456,11 @@ def main():
                        "scan is ~40 % and the bit-exact plane fit ~40 %) with the divergent candidate gathers keeping the texture "
                        "addresser ~75 % busy; see DESIGN.md section 6",
             "launches_per_step": int(live.sum()), "launches_per_graph_replay": int(args.graph), "algorithmic_bytes_per_launch": bytes_per_launch,
-            "launch_ms": [round(float(v), 4) for v in lms], "launch_points": [int(v) for v in pts_per_launch],
-            "measured": "HIP events around the graph replays of the last timed step on the handle's own stream, while the other "
-                        "handle's staging/sort kernels run concurrently",
+            "launches_measured": int(keep.get("launches", live.sum())),
+            "last_step_launch_ms": [round(float(v), 4) for v in lms], "last_step_launch_points": [int(v) for v in pts_per_launch],
+            "measured": "HIP events around every graph replay of every timed step on the handle's own stream (the other handle's "
+                        "staging/sort kernels run concurrently and stretch the launches they overlap); algorithmic bytes = 72 B x "
+                        "live point-iterations of the same steps",
         },
         "map_build_ms": prof0.map_build_ms, "map_upload_ms": prof0.map_upload_ms,
         "grid_cells": int(prof0.n_cells),
@@ -500,6 +516,31 @@ def main():
     # against the replicated map through the single-GPU path.  Registrations are independent objects, so this is
     # the natural partition of the batch (BASELINE.json configs[4]); it is reported next to `value`, which stays
     # the north_star's form (one registration's work spread over the ranks, all-reduce per GN iteration).
+    if runner and extras and args.shard == "map":
+        # the other partition SURVEY 8(e) allows: map replicated, every rank takes one N-th of every scan's workgroups
+        # (no halo, no ownership tests, balanced); same timed region, same collective
+        r2 = multi.ShardedRunner(pkg, map_xyz, rank, world, dist, torch, mode="scan", groups=2,
+                                 lookahead=max(args.lookahead, int(os.environ.get("BENCH_SHARD_LAG", "2"))), **kcfg_sh)
+
+        def scan_stream(n_steps):
+            for k in range(n_steps):
+                b = k % NB
+                r2.upload_raw(dev_rec[b].data_ptr(), batch_npts[b], stride)
+                r2.set_poses(poses0[b * B:(b + 1) * B])
+                r2.run()
+                r2.results(with_results=False)
+
+        scan_stream(max(2, args.warmup // 2))
+        sync_all()
+        t0 = time.perf_counter()
+        n_st = max(4, args.steps // 2)
+        scan_stream(n_st)
+        sync_all()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["scan_partition"] = {"value": B * n_st / float(t.item()), "unit": "registrations/s", "steps": n_st,
+                                 "note": "map replicated, scan workgroups dealt over the ranks, all-reduce of JtJ/Jtr per GN iteration"}
+        r2.close()
     if runner and world > 1 and extras:
         per = args.batch
         rep = pkg.ScanToMap(**kcfg)

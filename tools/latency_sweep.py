@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
-"""Single-registration latency (lio_s2m_register incl. H2D of the scan and D2H of the result) for the launch-loop options."""
+"""Single-registration latency (lio_s2m_register incl. H2D of the scan and D2H of the result) for the launch-loop options,
+against the 200-keyframe map of the bench case when its cache is given:  python tools/latency_sweep.py [case.npz]"""
 import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("lio-slam_amd")
 synth = importlib.import_module("lio-slam_amd.synth")
-case = synth.make_case("hdl64", n_keyframes=60, n_queries=16)
-qs = case["queries"]
+if len(sys.argv) > 1 and os.path.exists(sys.argv[1]):
+    z = np.load(sys.argv[1])
+    lens = z["lens"][:16]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    cat = z["scans"]
+    qs = [{"scan": np.ascontiguousarray(cat[offs[i]:offs[i + 1]]), "pose_init": z["poses0"][i]} for i in range(16)]
+    map_xyz = z["map"]
+else:
+    case = synth.make_case("hdl64", n_keyframes=60, n_queries=16)
+    qs, map_xyz = case["queries"], case["map"]
+print(f"# lio_s2m_register, hdl64 scans N_s ~ {np.mean([len(q['scan']) for q in qs]):.0f} vs N_m = {len(map_xyz)}, incl. H2D of the scan and D2H of the result")
 for name, cfg in [("eager look=1", dict(lookahead=1)), ("eager look=2", dict(lookahead=2)), ("eager look=3", dict(lookahead=3)),
                   ("graph 3", dict(use_graph=1, graph_iters=3)), ("graph 4", dict(use_graph=1, graph_iters=4)),
                   ("graph 6", dict(use_graph=1, graph_iters=6)), ("graph 8", dict(use_graph=1, graph_iters=8))]:
     s2m = pkg.ScanToMap(**cfg)
-    s2m.set_map(case["map"])
+    s2m.set_map(map_xyz)
     for q in qs[:4]:
         s2m.scan2MapOptimization(q["scan"], q["pose_init"])
     t = time.perf_counter()
@@ -21,5 +31,6 @@ for name, cfg in [("eager look=1", dict(lookahead=1)), ("eager look=2", dict(loo
         for q in qs:
             _, res, _ = s2m.scan2MapOptimization(q["scan"], q["pose_init"])
             iters.append(res.iters)
-    print(f"{name:14s} {1e3 * (time.perf_counter() - t) / (reps * len(qs)):.3f} ms per registration (mean GN iterations {np.mean(iters):.2f})")
+    dt = 1e3 * (time.perf_counter() - t) / (reps * len(qs))
+    print(f"{name:14s} {dt:.3f} ms per registration (mean GN iterations {np.mean(iters):.2f}, {1e3 * dt / np.mean(iters):.1f} us per iteration all included)")
     s2m.close()
