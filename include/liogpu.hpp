@@ -53,6 +53,20 @@ public:
         return rc;
     }
 
+    // The same on the `data` blob of msgIn->cloud_deskewed (sensor_msgs/PointCloud2, cloud_info.msg:27): what
+    // pcl::fromROSMsg(msgIn->cloud_deskewed, *laserCloudSurfLast) MO:440 + downsample + the loop do, minus the copy into
+    // a pcl::PointCloud.  point_step / off_x come from msg.point_step / the "x" entry of msg.fields.
+    int scan2MapOptimizationPC2(const void* data, size_t width_times_height, uint32_t point_step, uint32_t off_x, bool pin_host = false)
+    {
+        lio_pc2_layout lay{};
+        lay.point_step = point_step; lay.off_x = off_x; lay.off_intensity = -1; lay.off_ring = -1; lay.off_time = -1;
+        lay.pin_host = pin_host ? 1 : 0;
+        const int rc = lio_s2m_register_pc2(h_, data, width_times_height, &lay, transformTobeMapped, &last);
+        if (rc < 0) check(rc, "lio_s2m_register_pc2");
+        isDegenerate = last.is_degenerate != 0;
+        return rc;
+    }
+
     // ---- extension beyond this reference (upstream LIO-SAM) ----
     // kdtreeCornerFromMap->setInputCloud(laserCloudCornerFromMapDS)
     void setInputCloudCorner(const void* pts, size_t n, size_t stride_bytes)
