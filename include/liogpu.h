@@ -70,8 +70,10 @@ typedef struct lio_s2m_config {
     int32_t use_lds;         /* 1 = stage the workgroup's map region through LDS;
                                 0 (default) = stream the replicated neighbourhood rows     */
     int32_t sort_scan;       /* 1 = re-order scans by tiles at upload when the batch has >= 65536
-                                points (default), 2 = always, 0 = never;
-                                results are reported in the caller's order either way      */
+                                points (default), 2 = always, 0 = never, 3 = always and by the
+                                multi-kernel counting sort even when every scan fits the one-launch
+                                LDS sort (A/B and tests); results are reported in the caller's
+                                order either way                                            */
     int32_t cell_div;        /* k: cells per search radius (1..3, default 2); the candidate
                                 scan visits (2k+1)^3 cells, map rows are replicated (2k+1)^2 x */
     int32_t xcd_remap;       /* 1 (default) = XCD-aware workgroup order (L2 locality only)  */

@@ -67,6 +67,8 @@ void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const L
 void lio_launch_shard_cull(const LioIterParams& P, const float* block_box, int n_blocks, unsigned char* skip, hipStream_t s);
 void lio_launch_block_boxes(const LioBlockDesc* blocks, int n_blocks, const LioScanState* st, const float* sx, const float* sy,
                             const float* sz, float* box, hipStream_t s);
+void lio_launch_scan_sort_lds(const void* stage, size_t stride, const LioScanState* st, int n_scans, int max_pts, float tile0,
+                              int shard_axis, int* perm, float* x, float* y, float* z, hipStream_t s);
 void lio_launch_scan_bbox(const void* stage, size_t stride, const LioBlockDesc* prep_blocks, int n_prep_blocks,
                           const LioScanState* st, unsigned* bbox, hipStream_t s);
 void lio_launch_scan_tile_sort(const void* stage, size_t stride, int total_pts,

@@ -284,6 +284,110 @@ LIO_DEV int lio_tile_coord(float v, float origin, float inv_tile, int n)
     return (int)c;
 }
 
+// ---- the whole upload-time reorder of ONE scan by ONE workgroup, in LDS ------------------------------------------
+// For scans of at most 16384 points (every downsampled scan; raw sweeps take the multi-kernel path below): bounding box
+// (finite coordinates), tile grid (the same arithmetic as the host code of the multi-kernel path: tile edge doubled
+// until the grid has <= 262144 tiles), key = (linear tile id << 14) | caller index, bitonic sort of the 32-bit keys in
+// LDS, then perm[] and the SoA are written in sorted order.  Same permutation as the counting sort + rank sort (tile id
+// ascending, caller index ascending inside a tile), but no global atomics, no histogram over a million mostly empty
+// tiles, no host round trip for the bounding boxes, and deterministic by construction.
+#define LIO_SORT_THREADS 512
+__global__ __launch_bounds__(LIO_SORT_THREADS) void k_scan_sort_lds(const unsigned char* __restrict__ stage, size_t stride,
+                                                                    const LioScanState* __restrict__ st, float tile0, int shard_axis,
+                                                                    int* __restrict__ perm, float* __restrict__ x,
+                                                                    float* __restrict__ y, float* __restrict__ z)
+{
+    extern __shared__ unsigned s_key[];                    // np2 entries
+    __shared__ float s_mn[LIO_SORT_THREADS / 64][3], s_mx[LIO_SORT_THREADS / 64][3];
+    __shared__ float s_o[4];
+    __shared__ int s_nt[6];
+    const int scan = blockIdx.x;
+    const int n = st[scan].n_pts, base = st[scan].offset;
+    if (n <= 0) return;
+    const unsigned char* src = stage + (size_t)base * stride;
+    // 1. bounding box
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int i = threadIdx.x; i < n; i += LIO_SORT_THREADS) {
+        const float* p = reinterpret_cast<const float*>(src + (size_t)i * stride);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = p[a];
+            if (fabsf(v) <= 3.0e38f) { mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v); }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = s_mn[0][a]; hi[a] = s_mx[0][a];
+            for (int w = 1; w < LIO_SORT_THREADS / 64; ++w) { lo[a] = fminf(lo[a], s_mn[w][a]); hi[a] = fmaxf(hi[a], s_mx[w][a]); }
+            if (!(lo[a] <= hi[a])) { lo[a] = 0.0f; hi[a] = 0.0f; }
+        }
+        float tile = tile0, inv_tile;
+        int ntx, nty, ntz;
+        for (;;) {                                          // (the host loop of lio_s2m_batch_upload, verbatim)
+            inv_tile = 1.0f / tile;
+            const double ex = floor(((double)hi[0] - lo[0]) * inv_tile) + 1.0, ey = floor(((double)hi[1] - lo[1]) * inv_tile) + 1.0,
+                         ez = floor(((double)hi[2] - lo[2]) * inv_tile) + 1.0;
+            if (ex * ey * ez <= 262144.0) { ntx = (int)ex; nty = (int)ey; ntz = (int)ez; break; }
+            tile *= 2.0f;
+        }
+        s_o[0] = lo[0]; s_o[1] = lo[1]; s_o[2] = lo[2]; s_o[3] = inv_tile;
+        int kx = 1, ky = ntx, kz = ntx * nty;               // x fastest; with a sharded map the shard axis slowest
+        if (shard_axis == 0) { kz = 1; ky = ntz; kx = ntz * nty; }
+        else if (shard_axis == 1) { kx = 1; kz = ntx; ky = ntx * ntz; }
+        s_nt[0] = ntx; s_nt[1] = nty; s_nt[2] = ntz; s_nt[3] = kx; s_nt[4] = ky; s_nt[5] = kz;
+    }
+    __syncthreads();
+    // 2. keys
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += LIO_SORT_THREADS) {
+        unsigned k = 0xffffffffu;
+        if (i < n) {
+            const float* p = reinterpret_cast<const float*>(src + (size_t)i * stride);
+            const int tx = lio_tile_coord(p[0], s_o[0], s_o[3], s_nt[0]);
+            const int ty = lio_tile_coord(p[1], s_o[1], s_o[3], s_nt[1]);
+            const int tz = lio_tile_coord(p[2], s_o[2], s_o[3], s_nt[2]);
+            k = ((unsigned)(tx * s_nt[3] + ty * s_nt[4] + tz * s_nt[5]) << 14) | (unsigned)i;
+        }
+        s_key[i] = k;
+    }
+    __syncthreads();
+    // 3. bitonic sort (ascending; the 0xffffffff padding sinks to the end)
+    for (int size = 2; size <= np2; size <<= 1) {
+        for (int stp = size >> 1; stp >= 1; stp >>= 1) {
+            for (int i = threadIdx.x; i < (np2 >> 1); i += LIO_SORT_THREADS) {
+                const int lo = ((i / stp) * (stp << 1)) + (i % stp), hi = lo + stp;
+                const bool up = ((lo & size) == 0);
+                const unsigned a = s_key[lo], b = s_key[hi];
+                if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // 4. permutation and SoA in sorted order
+    for (int j = threadIdx.x; j < n; j += LIO_SORT_THREADS) {
+        const int i = (int)(s_key[j] & 0x3fffu);
+        const float* p = reinterpret_cast<const float*>(src + (size_t)i * stride);
+        perm[base + j] = base + i;
+        x[base + j] = p[0]; y[base + j] = p[1]; z[base + j] = p[2];
+    }
+}
+
 // Bounding box of every scan of the batch (finite coordinates only), one workgroup per 256 points:
 // bbox[scan][0..2] = min, [3..5] = max as order-preserving uints (initialised to ~0 / 0 by the host).
 __global__ __launch_bounds__(256) void k_scan_bbox(const unsigned char* __restrict__ stage, size_t stride,
@@ -1055,6 +1159,16 @@ void lio_launch_block_boxes(const LioBlockDesc* blocks, int n_blocks, const LioS
 {
     if (n_blocks <= 0) return;
     hipLaunchKernelGGL(k_block_boxes, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, blocks, st, sx, sy, sz, box);
+}
+
+void lio_launch_scan_sort_lds(const void* stage, size_t stride, const LioScanState* st, int n_scans, int max_pts, float tile0,
+                              int shard_axis, int* perm, float* x, float* y, float* z, hipStream_t s)
+{
+    if (n_scans <= 0) return;
+    int np2 = 1;
+    while (np2 < max_pts) np2 <<= 1;
+    hipLaunchKernelGGL(k_scan_sort_lds, dim3(n_scans), dim3(LIO_SORT_THREADS), (size_t)np2 * sizeof(unsigned), s,
+                       (const unsigned char*)stage, stride, st, tile0, shard_axis, perm, x, y, z);
 }
 
 void lio_launch_scan_bbox(const void* stage, size_t stride, const LioBlockDesc* prep_blocks, int n_prep_blocks,

@@ -79,6 +79,7 @@ struct lio_s2m_handle {
     std::vector<LioBlockDesc> v_blocks_sorted;       // v_blocks re-ordered by scan position (sort_batch)
     std::vector<int> v_order, v_first, v_first_orig;
     bool defer_sync = false;                         // lio_s2m_register: one sync at the end of the call
+    bool async_upload = false;                       // lio_s2m_batch_upload_async: wait for the H2D copy only
     float* d_poses = nullptr; size_t cap_poses = 0;
     float* d_summary = nullptr; size_t cap_summary = 0;   // [n_scans][10] compact results (lio_s2m_batch_results without `results`)
     float* h_summary = nullptr; size_t cap_h_summary = 0; // pinned
@@ -648,8 +649,10 @@ extern "C" int lio_s2m_batch_upload_async(lio_s2m_handle* h, int32_t n_scans, co
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     const bool keep = h->defer_sync;
     h->defer_sync = true;
+    h->async_upload = true;
     const int rc = lio_s2m_batch_upload(h, n_scans, scans, n_pts, stride);
     h->defer_sync = keep;
+    h->async_upload = false;
     return rc;
 }
 
@@ -799,6 +802,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     // copied one by one; a contiguous batch that already lives in THIS device's memory is not copied at all: the
     // sort kernels read it in place (it must stay valid until the next lio_s2m_batch_sync / _results).
     const unsigned char* stage = h->d_stage;
+    bool host_copy = false;            // the caller's (host) buffers are in flight: they are borrowed until the copy is done
     {
         bool contiguous = true;
         for (int s = 0; s + 1 < n_scans && contiguous; ++s)
@@ -814,7 +818,9 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
             stage = (const unsigned char*)scans[0];
         } else if (contiguous && total) {
             HIPCHK(hipMemcpyAsync(h->d_stage, scans[0], total * stride, hipMemcpyDefault, h->stream));
+            host_copy = true;
         } else {
+            host_copy = true;
             size_t o = 0;
             for (int s = 0; s < n_scans; ++s) {
                 if (n_pts[s])
@@ -822,6 +828,10 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
                 o += n_pts[s];
             }
         }
+    }
+    if (host_copy && h->async_upload) {
+        HIPCHK(hipEventRecord(h->ev_map[0], h->stream));   // (async upload: wait for the H2D only, the sort stays in flight)
+        HIPCHK(hipEventSynchronize(h->ev_map[0]));
     }
     h->last_stage = stage; h->last_stride = stride; h->last_xyz_off = h->xyz_off;
     stage += h->xyz_off;                                 // (x, y, z are read at +0, +4, +8 from here; xyz_off + 12 <= stride)
@@ -858,7 +868,14 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     tiles.clear(); prep.clear();
     h->sorted = false;
     // the tile sort pays for itself on batches; a lone small scan skips its eight launches
-    if (total && (h->cfg.sort_scan == 2 || (h->cfg.sort_scan == 1 && total >= 65536))) {
+    const bool want_sort = total && (h->cfg.sort_scan >= 2 || (h->cfg.sort_scan == 1 && total >= 65536));
+    if (want_sort && max_n <= 16384 && h->cfg.sort_scan != 3) {
+        // every scan fits one workgroup's LDS: bounding box, tile keys, sort and gather in ONE launch, nothing read back
+        HIPCHK(lio_grow(&h->d_perm, &h->cap_perm, tt));
+        lio_launch_scan_sort_lds(stage, stride, h->d_state, n_scans, (int)max_n, h->cfg.tile_size > 0.0f ? h->cfg.tile_size : 4.0f,
+                                 h->shard.axis, h->d_perm, h->d_sx, h->d_sy, h->d_sz, h->stream);
+        h->sorted = true;
+    } else if (want_sort) {
         // scan-local tile grids from the scans' bounding boxes, reduced on the device (the caller's memory is
         // never read by the host: it may be pinned, pageable or device memory)
         for (int s = 0; s < n_scans; ++s) {

@@ -137,3 +137,29 @@ def test_oversized_tiles_are_ordered_deterministically(pkg, oracle, synth):
     np.testing.assert_allclose(outs[3][0], outs[0][0], atol=1e-5)
     po, ro, _, _ = oracle.scan2map(oracle.default_config(knn_mode=1, n_threads=8), raws[0], case["map"], poses0[0])
     assert np.abs(outs[0][0][0][3:] - po[3:]).max() <= 1e-5 and np.abs(outs[0][0][0][:3] - po[:3]).max() <= 1e-6
+
+
+def test_one_launch_lds_sort_equals_the_counting_sort(pkg, small_case):
+    """Scans of at most 16384 points are reordered by ONE launch (k_scan_sort_lds: box, tile keys, bitonic sort in LDS,
+    gather); it must produce the permutation of the multi-kernel counting sort + rank sort (cfg.sort_scan = 3), so every
+    sum -- and with it every bit of the result -- is the same.  Ragged batch, tiny and empty-ish scans included."""
+    qs = small_case["queries"]
+    scans = [q["scan"] for q in qs] + [qs[0]["scan"][:20], qs[1]["scan"][::2], qs[2]["scan"][:1], qs[0]["scan"][:257]]
+    poses0 = np.stack([q["pose_init"] for q in qs] + [qs[0]["pose_init"], qs[1]["pose_init"], qs[2]["pose_init"], qs[0]["pose_init"]])
+    outs = []
+    for mode in (2, 3):
+        for tile in (0.0, 1.5):
+            s = pkg.ScanToMap(sort_scan=mode, tile_size=tile, record_corr_iter=1)
+            s.set_map(small_case["map"])
+            s.batch_upload(scans); s.batch_set_poses(poses0); s.batch_run()
+            p, r = s.batch_results()
+            outs.append((mode, tile, p, [np.array(x.AtA, np.float32).view(np.uint32) for x in r], s.get_correspondences(1)))
+            s.close()
+    for tile in (0.0, 1.5):
+        a = next(o for o in outs if o[0] == 2 and o[1] == tile)
+        b = next(o for o in outs if o[0] == 3 and o[1] == tile)
+        np.testing.assert_array_equal(a[2], b[2])
+        for u, v in zip(a[3], b[3]):
+            np.testing.assert_array_equal(u, v)
+        for u, v in zip(a[4], b[4]):
+            np.testing.assert_array_equal(u, v)
