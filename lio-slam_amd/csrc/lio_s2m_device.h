@@ -270,6 +270,12 @@ LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, 
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         n0 = f0; n1 = f1; n2 = f2; n3 = f3;
     }
+#elif LIO_PREFETCH == 0
+    // no register double-buffering: the other waves of the SIMD cover the load (A/B experiment)
+    for (unsigned j = beg; j < end; j += 4, p += 4) {
+        const float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+        lio_knn_group(c0, c1, c2, c3, QX, QY, QZ, top);
+    }
 #else
     float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
     for (unsigned j = beg + 4; j < end; j += 4) {

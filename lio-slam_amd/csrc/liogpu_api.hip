@@ -1669,6 +1669,7 @@ extern "C" int lio_s2m_get_correspondences(lio_s2m_handle* h, int32_t scan, uint
     }
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
+    { const int rcc = lio_run_continue(h, true); if (rcc != LIO_OK) return rcc; }   // (a run started by batch_run may still be pending)
     const size_t off = (size_t)h->h_state[scan].offset, n = (size_t)h->h_state[scan].n_pts;
     if (n == 0) return LIO_OK;
     if (flag) HIPCHK(hipMemcpyAsync(flag, h->d_rec_flag + off, n, hipMemcpyDeviceToHost, h->stream));
