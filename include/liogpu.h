@@ -231,6 +231,13 @@ int  lio_s2m_debug_stamps(lio_s2m_handle *h, long long *out, size_t cap_entries)
 int  lio_s2m_set_stream(lio_s2m_handle *h, void *hip_stream);
 int  lio_s2m_set_global_grid(lio_s2m_handle *h, const float origin[3], const int32_t dims[3]);
 int  lio_s2m_set_shard(lio_s2m_handle *h, int32_t axis, int32_t lo, int32_t hi);
+/* The whole slab plan instead of this rank's range: rank r of n_ranks owns cells [bounds[r], bounds[r+1]) and holds the
+ * map of [bounds[r] - halo_cells, bounds[r+1] + halo_cells).  With halo_cells > 1 a workgroup of scan points (256
+ * consecutive points of the tile-sorted scan) whose extent fits the held region of the rank owning its middle is
+ * processed WHOLLY by that rank and skipped by all others; longer workgroups keep per-point ownership.  Same results;
+ * no wave runs for a handful of owned lanes.  Every rank must be given identical bounds and halo. */
+int  lio_s2m_set_shard_plan(lio_s2m_handle *h, int32_t axis, int32_t n_ranks, int32_t rank, const int32_t *bounds,
+                            int32_t halo_cells);
 /* Alternative partition: the map is replicated, every rank processes each world-th
  * workgroup of every scan (call before lio_s2m_batch_upload); same iter_partial / all-reduce /
  * iter_apply protocol.  No halo, no ownership tests, perfectly balanced. */

@@ -122,7 +122,7 @@ EXPORTS = [
     "lio_s2m_get_corner_correspondences", "lio_feature_default_config", "lio_extract_features",
     "lio_range_image_default_config", "lio_range_image",
     "lio_s2m_share_map", "lio_s2m_batch_upload_async", "lio_host_alloc", "lio_host_free", "lio_host_register",
-    "lio_host_unregister", "lio_s2m_register_pc2", "lio_deskew_pc2", "lio_kf_store_add_device", "lio_kf_store_add_from_handle",
+    "lio_host_unregister", "lio_s2m_set_shard_plan", "lio_s2m_register_pc2", "lio_deskew_pc2", "lio_kf_store_add_device", "lio_kf_store_add_from_handle",
 ]
 
 
@@ -171,6 +171,7 @@ def load_library():
     L.lio_s2m_set_global_grid.argtypes = [vp, C.POINTER(f32), C.POINTER(i32)]
     L.lio_s2m_set_shard.argtypes = [vp, i32, i32, i32]
     L.lio_s2m_set_scan_shard.argtypes = [vp, i32, i32]
+    L.lio_s2m_set_shard_plan.argtypes = [vp, i32, i32, i32, C.POINTER(i32), i32]
     L.lio_s2m_batch_begin.argtypes = [vp]
     L.lio_s2m_batch_iter_partial.argtypes = [vp, vp]
     L.lio_s2m_batch_iter_apply.argtypes = [vp, vp]
@@ -402,6 +403,10 @@ class ScanToMap:
 
     def set_shard(self, axis, lo, hi):
         _check(self.lib.lio_s2m_set_shard(self.h, axis, lo, hi), "lio_s2m_set_shard")
+
+    def set_shard_plan(self, axis, rank, bounds, halo_cells):
+        b = (C.c_int32 * len(bounds))(*[int(v) for v in bounds])
+        _check(self.lib.lio_s2m_set_shard_plan(self.h, axis, len(bounds) - 1, rank, b, halo_cells), "lio_s2m_set_shard_plan")
 
     def set_scan_shard(self, rank, world):
         _check(self.lib.lio_s2m_set_scan_shard(self.h, rank, world), "lio_s2m_set_scan_shard")

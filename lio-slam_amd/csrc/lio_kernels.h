@@ -30,7 +30,8 @@ struct LioIterParams {
     int* rec_nn;
     float* d5_cache;               // [total_pts] squared 5th-neighbour distance of the previous iteration (-1: none), or null
     long long* stamps;             // diagnostic phase clock: [block][wave][8] cycle counters, or null
-    const unsigned char* blk_skip; // map sharding: [n_blocks] workgroups k_shard_cull has already answered for, or null
+    const unsigned char* blk_skip; // map sharding: [n_blocks] per-workgroup decision of k_shard_cull (0 per-point ownership, 1 answered
+                                   // for by the cull, 2 wholly ours), or null
 };
 
 // Arguments of the split pipeline's kernels: the fused kernel's plus the neighbour cache and the work list.
@@ -64,7 +65,8 @@ void lio_launch_split_iteration(const LioSplitParams& S, int n_blocks, hipStream
 void lio_launch_pack_summary(const LioScanState* st, int n_scans, float* out, hipStream_t s);
 void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
                       int* n_active, hipStream_t s);
-void lio_launch_shard_cull(const LioIterParams& P, const float* block_box, int n_blocks, unsigned char* skip, hipStream_t s);
+void lio_launch_shard_cull(const LioIterParams& P, int n_ranks, int rank, int halo, const int* bounds, const float* block_box,
+                           int n_blocks, unsigned char* skip, hipStream_t s);
 void lio_launch_block_boxes(const LioBlockDesc* blocks, int n_blocks, const LioScanState* st, const float* sx, const float* sy,
                             const float* sz, float* box, hipStream_t s);
 void lio_launch_scan_sort_lds(const void* stage, size_t stride, const LioScanState* st, int n_scans, int max_pts, float tile0,

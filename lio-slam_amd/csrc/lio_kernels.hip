@@ -607,24 +607,38 @@ __global__ __launch_bounds__(LIO_BLOCK) void k_block_boxes(const LioBlockDesc* _
     }
 }
 
-// Map sharding: cull whole workgroups BEFORE the association launch.  One wave per workgroup of the list: the
-// workgroup's points sit in a box (lidar frame, k_block_boxes); its eight corners, transformed, bound every
-// transformed point along the shard axis (an affine image of a box lies inside the hull of the mapped corners).  If
-// that interval -- widened against fp32 rounding -- misses the cells this rank owns, no point of the workgroup can
-// be owned here: this kernel reports the all-zero partial sum and the arrival in the workgroup's place, drops the
-// points' search bounds, and flags the workgroup so that k_s2m_iterate returns at once.  Every other workgroup goes
-// through the exact per-point ownership test of k_s2m_iterate, so the cull can never change a result.
-__global__ __launch_bounds__(256) void k_shard_cull(LioIterParams P, const float* __restrict__ block_box, int n_blocks,
+// Map sharding: decide the fate of whole workgroups BEFORE the association launch.  One wave per workgroup of the
+// list: the workgroup's points sit in a box (lidar frame, k_block_boxes); its eight corners, transformed, bound every
+// transformed point along the shard axis (an affine image of a box lies inside the hull of the mapped corners), giving
+// a cell interval [c_lo, c_hi] (widened against fp32 rounding).  Every rank evaluates the same rule on the same data:
+//   * WHOLE-WORKGROUP OWNERSHIP (plan.n_ranks > 0): let R be the rank owning the interval's middle cell.  If the
+//     interval, plus the one cell a neighbour search can reach, lies inside R's slab extended by the plan's halo -- the
+//     part of the map R holds --, R processes ALL points of the workgroup (mode 2, no per-point test) and every other
+//     rank skips it (mode 1).  A point is then processed where its whole workgroup is, with every map point within
+//     1 m present, so its 5-NN set is the unsharded one; no wave runs for a handful of owned lanes any more.
+//   * otherwise (a workgroup longer than the halo allows, or no plan): per-point ownership by the cell of the point's
+//     own position (mode 0) on the ranks whose slab the interval meets, skipped (mode 1) elsewhere.
+// For a skipped workgroup this kernel reports the all-zero partial sum and the arrival in its place and drops the
+// points' search bounds; k_s2m_iterate returns on the flag before loading a point.  The rule never changes a result.
+struct LioShardPlan {
+    int n_ranks;            // 0 = no whole-workgroup ownership (lio_s2m_set_shard)
+    int rank;
+    int halo;               // cells of map held beyond the slab on each side (>= 1)
+    int bounds[9];          // rank r owns cells [bounds[r], bounds[r+1])
+};
+
+__global__ __launch_bounds__(256) void k_shard_cull(LioIterParams P, LioShardPlan plan, const float* __restrict__ block_box, int n_blocks,
                                                     unsigned char* __restrict__ skip)
 {
-    const int i = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // eight lanes per workgroup of the list (one per corner of its box), eight workgroups per wave
+    const int lane = threadIdx.x & 63, c = lane & 7;
+    const int i = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 8 + (lane >> 3);
     if (i >= n_blocks) return;
     const LioBlockDesc bd = P.blocks[i];
     const LioScanState* st = &P.state[bd.scan];
-    if (st->done) { if (lane == 0) skip[i] = 0; return; }
+    if (st->done) { if (c == 0) skip[i] = 0; return; }
     const int base = st->offset, ax = P.shard.axis;
     const float* bb = block_box + (size_t)((base + bd.first) / LIO_BLOCK + bd.scan) * 6;
-    const int c = lane & 7;
     const float bx = (c & 1) ? bb[3] : bb[0], by = (c & 2) ? bb[4] : bb[1], bz = (c & 4) ? bb[5] : bb[2];
     const float qa = st->T[ax * 4 + 0] * bx + st->T[ax * 4 + 1] * by + st->T[ax * 4 + 2] * bz + st->T[ax * 4 + 3];
     float lo = qa, hi = qa;
@@ -635,20 +649,30 @@ __global__ __launch_bounds__(256) void k_shard_cull(LioIterParams P, const float
     int c_hi = lio_cell_coord(hi + eps, P.shard.gorigin, P.shard.inv_cell, P.shard.gdim);
     c_lo = min(max(c_lo, 0), P.shard.gdim - 1);
     c_hi = min(max(c_hi, 0), P.shard.gdim - 1);
-    // (a workgroup without finite points has an empty box, lo > hi or NaN: never culled, the exact test handles it)
-    const bool culled = (lo <= hi) && (c_hi < P.shard.lo || c_lo >= P.shard.hi);
-    if (lane == 0) skip[i] = culled ? 1 : 0;
-    if (!culled) return;
+    int mode = 0;
+    if (lo <= hi) {                                         // (an empty box -- no finite point -- stays on the exact path)
+        bool whole = false;
+        if (plan.n_ranks > 0) {
+            const int mid = (c_lo + c_hi) >> 1;
+            int r = 0;
+            while (r + 1 < plan.n_ranks && mid >= plan.bounds[r + 1]) ++r;
+            whole = (c_lo - 1 >= plan.bounds[r] - plan.halo) && (c_hi + 1 < plan.bounds[r + 1] + plan.halo);
+            if (whole) mode = (r == plan.rank) ? 2 : 1;
+        }
+        if (!whole && (c_hi < P.shard.lo || c_lo >= P.shard.hi)) mode = 1;
+    }
+    if (c == 0) skip[i] = (unsigned char)mode;
+    if (mode != 1) return;
     if (P.d5_cache) {                                       // the search bound of a point is only valid from one pass to the very next
-        for (int j = lane; j < LIO_BLOCK; j += 64)
+        for (int j = c; j < LIO_BLOCK; j += 8)
             if (bd.first + j < st->n_pts) P.d5_cache[base + bd.first + j] = -1.0f;
     }
     double* part0 = P.partials + ((size_t)bd.scan * P.max_blk + bd.blk) * LIO_SUMS;
-    if (lane < 28) __hip_atomic_store(part0 + lane, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) {
+    for (int j = c; j < 28; j += 8) __hip_atomic_store(part0 + j, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (every lane of the wave has drained its stores before any lane arrives)
+    if (c == 0) {
         const unsigned old = atomicAdd(&P.arrive[bd.scan], 1u);
-        // every workgroup of the scan culled on this rank: its (all-zero) sums are already in sums_out; re-arm the counter
+        // every workgroup of the scan skipped on this rank: its (all-zero) sums are already in sums_out; re-arm the counter
         if (old == (unsigned)bd.n_blk - 1u) P.arrive[bd.scan] = 0;
     }
 }
@@ -746,7 +770,10 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
         const int n8 = gridDim.x >> 3;                     // full groups of 8
         if (wg < n8 * 8) wg = (wg & 7) * n8 + (wg >> 3);
     }
-    if (P.blk_skip != nullptr && P.blk_skip[wg]) return;   // map sharding: k_shard_cull has already reported for this workgroup
+    // map sharding, decided per workgroup by k_shard_cull: 1 = it has already reported for this workgroup (not ours),
+    // 2 = the WHOLE workgroup is ours (no per-point ownership test), 0 = per-point ownership
+    const int wg_mode = P.blk_skip != nullptr ? (int)P.blk_skip[wg] : 0;
+    if (wg_mode == 1) return;
     const LioBlockDesc bd = P.blocks[wg];
     LioScanState* st = &P.state[bd.scan];
     if (st->done) return;                                  // workgroup-uniform
@@ -786,7 +813,7 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
         qy[pp] = T[4] * px[pp] + T[5] * py[pp] + T[6]  * pz[pp] + T[7];
         qz[pp] = T[8] * px[pp] + T[9] * py[pp] + T[10] * pz[pp] + T[11];
         bool a = inr[pp];
-        if (P.shard.axis >= 0) {                                     // owner-computes (multi-GPU)
+        if (P.shard.axis >= 0 && wg_mode != 2) {                     // owner-computes (multi-GPU)
             const float qa = P.shard.axis == 0 ? qx[pp] : (P.shard.axis == 1 ? qy[pp] : qz[pp]);
             int gc = lio_cell_coord(qa, P.shard.gorigin, P.shard.inv_cell, P.shard.gdim);
             gc = min(max(gc, 0), P.shard.gdim - 1);
@@ -1148,10 +1175,14 @@ void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const L
     hipLaunchKernelGGL(k_s2m_apply, dim3(n_scans), dim3(64), 0, s, st, n_scans, sums, c, n_active);
 }
 
-void lio_launch_shard_cull(const LioIterParams& P, const float* block_box, int n_blocks, unsigned char* skip, hipStream_t s)
+void lio_launch_shard_cull(const LioIterParams& P, int n_ranks, int rank, int halo, const int* bounds, const float* block_box,
+                           int n_blocks, unsigned char* skip, hipStream_t s)
 {
     if (n_blocks <= 0) return;
-    hipLaunchKernelGGL(k_shard_cull, dim3((n_blocks + 3) / 4), dim3(256), 0, s, P, block_box, n_blocks, skip);
+    LioShardPlan plan;
+    plan.n_ranks = n_ranks; plan.rank = rank; plan.halo = halo;
+    for (int r = 0; r < 9; ++r) plan.bounds[r] = (n_ranks > 0 && r <= n_ranks) ? bounds[r] : 0;
+    hipLaunchKernelGGL(k_shard_cull, dim3((n_blocks + 31) / 32), dim3(256), 0, s, P, plan, block_box, n_blocks, skip);
 }
 
 void lio_launch_block_boxes(const LioBlockDesc* blocks, int n_blocks, const LioScanState* st, const float* sx, const float* sy,

@@ -63,15 +63,15 @@ def plan_shards(map_xyz, world, cell=None, load_xyz=None):
     return {"origin": origin, "dims": dims, "cell": cell, "inv_cell": inv_cell, "axis": axis, "bounds": bounds}
 
 
-def shard_points(map_xyz, plan, rank):
-    """Indices (ascending) of the map points rank `rank` must hold: its slab + 1-cell halo."""
+def shard_points(map_xyz, plan, rank, halo=1):
+    """Indices (ascending) of the map points rank `rank` must hold: its slab + `halo` cells on each side."""
     map_xyz = np.asarray(map_xyz, np.float32)
     a = plan["axis"]
     lo, hi = int(plan["bounds"][rank]), int(plan["bounds"][rank + 1])
     if len(map_xyz) == 0:
         return np.zeros(0, np.int64)
     c = np.clip(cell_coord(map_xyz[:, a], plan["origin"][a], plan["inv_cell"], plan["dims"][a]), 0, plan["dims"][a] - 1)
-    return np.nonzero((c >= lo - 1) & (c < hi + 1))[0]
+    return np.nonzero((c >= lo - halo) & (c < hi + halo))[0]
 
 
 def owner_mask(q_world, plan, rank):
@@ -106,7 +106,7 @@ class ShardedRunner:
     """
 
     def __init__(self, pkg, map_xyz, rank, world, dist, torch, mode="map", groups=2, deterministic=False,
-                 lookahead=2, load_xyz=None, **cfg):
+                 lookahead=2, load_xyz=None, halo_cells=16, **cfg):
         self.rank, self.world, self.dist, self.torch = rank, world, dist, torch
         self.mode, self.deterministic, self.lookahead = mode, deterministic, lookahead
         self.handles = []
@@ -118,7 +118,9 @@ class ShardedRunner:
             if not cell > 0:
                 cell = default_cell(cfg.get("max_sq_dist", 1.0))
             self.plan = plan_shards(map_xyz, world, cell=cell, load_xyz=load_xyz)
-            self.idx = shard_points(map_xyz, self.plan, rank)
+            # a halo wider than the one cell exactness needs lets whole workgroups be owned by one rank (lio_s2m_set_shard_plan)
+            self.halo = max(1, int(halo_cells))
+            self.idx = shard_points(map_xyz, self.plan, rank, self.halo)
         else:
             self.idx = np.arange(len(map_xyz))
         # one stream per sub-batch: the latency-bound pieces of one sub-batch (all-reduce, solve) run under the
@@ -130,7 +132,7 @@ class ShardedRunner:
             if mode == "map":
                 s2m.set_map(np.ascontiguousarray(map_xyz[self.idx]))
                 s2m.set_global_grid([float(v) for v in self.plan["origin"]], [int(v) for v in self.plan["dims"]])
-                s2m.set_shard(self.plan["axis"], int(self.plan["bounds"][rank]), int(self.plan["bounds"][rank + 1]))
+                s2m.set_shard_plan(self.plan["axis"], rank, [int(v) for v in self.plan["bounds"]], self.halo)
             else:
                 s2m.set_map(map_xyz)
                 s2m.set_scan_shard(rank, world)

@@ -16,6 +16,9 @@ scans1 = [np.ascontiguousarray(cat[offs[i]:offs[i + 1]]) for i in range(len(lens
 map_xyz, poses1 = z["map"], z["poses0"][:512]
 
 
+HALO = int(os.environ.get("SHARD_HALO", "16"))
+
+
 def one(mode, world, rank, balance="load"):
     s2m = pkg.ScanToMap(profile=1, max_iters=2)
     if mode == "map":
@@ -23,10 +26,10 @@ def one(mode, world, rank, balance="load"):
         load = np.concatenate([mg.transform_f32(synth.pose_matrix(poses1[i])[:3].astype(np.float32).reshape(12), scans1[i][::16])
                                for i in range(0, len(scans1), 4)]) if balance == "load" else None
         plan = mg.plan_shards(map_xyz, world, load_xyz=load)
-        idx = mg.shard_points(map_xyz, plan, rank)
+        idx = mg.shard_points(map_xyz, plan, rank, HALO)
         s2m.set_map(np.ascontiguousarray(map_xyz[idx]))
         s2m.set_global_grid([float(v) for v in plan["origin"]], [int(v) for v in plan["dims"]])
-        s2m.set_shard(plan["axis"], int(plan["bounds"][rank]), int(plan["bounds"][rank + 1]))
+        s2m.set_shard_plan(plan["axis"], rank, [int(v) for v in plan["bounds"]], HALO)
     else:
         s2m.set_map(map_xyz)
         s2m.set_scan_shard(rank, world)
