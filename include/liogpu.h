@@ -88,8 +88,9 @@ typedef struct lio_s2m_config {
                                 search by the distances to its previous 5 neighbours (exact:
                                 the candidate run shrinks, the result does not change)      */
     int32_t pipeline;        /* 0 / 1 = one fused launch per GN iteration (k_s2m_iterate); 2 = split: neighbour
-                                certificate / candidate scan / fit as three launches (identical results;
-                                measured slower on MI355X, kept as an option with its evidence)          */
+                                certificate / candidate scan / fit as three launches; 3 = the fused launch with
+                                the certificate inside (k_s2m_iterate_cert).  Identical results; 2 measured
+                                slower and 3 no faster on MI355X, both kept as options with their evidence   */
     int32_t n_devices;       /* 1 (default) = the single device `device_id`.  > 1: in-library multi-GPU -- the local
                                 map is cut into slabs (+ one-cell halo) over device_ids[0..n_devices), every
                                 registration's points are processed by the device owning their map cell and the

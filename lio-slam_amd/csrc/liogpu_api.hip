@@ -114,6 +114,7 @@ struct lio_s2m_handle {
     long long* d_stamps = nullptr; size_t cap_stamps = 0;
     // split pipeline (cfg.pipeline): neighbour cache + per-iteration scan work list
     bool split = false;               // the resident batch runs k_s2m_cert / _scan / _fit instead of k_s2m_iterate
+    bool certk = false;               // the resident batch runs k_s2m_iterate_cert (cfg.pipeline = 3)
     bool cache_dirty = true;          // map or batch changed: the neighbour cache must be dropped before the next run
     std::vector<LioGroupDesc> v_groups;
     LioGroupDesc* d_groups = nullptr; size_t cap_groups = 0;
@@ -786,7 +787,9 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     // (lio_split.hip).  Bit-identical, and measured SLOWER than the fused launch on an MI355X (DESIGN.md section 6:
     // 2.2 ms vs 1.5 ms of kernel time per 512-scan step), so auto (0) means fused.
     h->split = ppt == 1 && !h->cfg.use_lds && h->cfg.profile != 2 && h->cfg.pipeline == 2;
-    if (h->split) {
+    // cfg.pipeline = 3: the fused launch with the certificate inside (k_s2m_iterate_cert, lio_cert.hip)
+    h->certk = ppt == 1 && !h->cfg.use_lds && h->cfg.profile != 2 && h->cfg.pipeline == 3;
+    if (h->split || h->certk) {
         HIPCHK(lio_grow(&h->d_cache_idx, &h->cap_cache_idx, tt * LIO_CACHE_K));
         HIPCHK(lio_grow(&h->d_cache_q, &h->cap_cache_q, tt));
         HIPCHK(lio_grow(&h->d_pt_flag, &h->cap_pt_flag, tt));
@@ -886,6 +889,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         HIPCHK(hipMemcpyAsync(h->d_blocks, blocks.data(), blocks.size() * sizeof(LioBlockDesc),
                               hipMemcpyHostToDevice, h->stream));
     if (h->split) { const int rcg = lio_build_groups(h, blocks); if (rcg != LIO_OK) return rcg; }
+    else h->v_groups.clear();
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state.data(), (size_t)n_scans * sizeof(LioScanState),
                           hipMemcpyHostToDevice, h->stream));
     std::vector<LioScanTiles>& tiles = h->v_tiles;
@@ -1214,6 +1218,11 @@ static void lio_launch_gn(lio_s2m_handle* h, const LioIterParams& P, const LioIt
         LioSplitParams S;
         lio_fill_split(h, P, S);
         lio_launch_split_iteration(S, h->n_blocks, h->stream);
+    } else if (h->certk) {
+        LioSplitParams S;
+        lio_fill_split(h, P, S);
+        S.it.d5_cache = nullptr;
+        lio_launch_iterate_cert(S, h->n_blocks, h->stream);
     } else {
         lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
     }
@@ -1235,7 +1244,7 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->c, h->d_active, h->stream);
     if (h->split && h->cfg.profile && h->d_split_stats)
         HIPCHK(hipMemsetAsync(h->d_split_stats, 0, h->v_groups.size() * LIO_MAX_ITERS * sizeof(int), h->stream));
-    if (h->split && h->cache_dirty) {
+    if ((h->split || h->certk) && h->cache_dirty) {
         // 0xff bytes = NaN in the bound word: "no cache" (the `>= 0` test fails)
         HIPCHK(hipMemsetAsync(h->d_cache_q, 0xff, (h->total_pts ? h->total_pts : 1) * sizeof(float4), h->stream));
         h->cache_dirty = false;
@@ -1573,7 +1582,7 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
     }
     h->prof.n_units = n_units;
     h->prof.unit_iters = h->unit_iters;
-    h->prof.pipeline = h->split ? 2 : 1;
+    h->prof.pipeline = h->split ? 2 : (h->certk ? 3 : 1);
     memset(h->prof.cert_points, 0, sizeof(h->prof.cert_points));
     memset(h->prof.scan_points, 0, sizeof(h->prof.scan_points));
     if (h->split && h->cfg.profile && h->d_split_stats && !h->v_groups.empty()) {

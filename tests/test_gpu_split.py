@@ -1,5 +1,6 @@
-"""The split Gauss-Newton pipeline (cfg.pipeline = 2: neighbour certificate / balanced candidate scan /
-fit, lio-slam_amd/csrc/lio_split.hip) against the fused launch (pipeline = 1) and the CPU oracle.
+"""The neighbour certificate -- as the split Gauss-Newton pipeline (cfg.pipeline = 2: certificate / candidate scan / fit as
+three launches, lio-slam_amd/csrc/lio_split.hip) and inside the fused launch (cfg.pipeline = 3, k_s2m_iterate_cert,
+lio_cert.hip) -- against the plain fused launch (pipeline = 1) and the CPU oracle.
 
 The certificate replaces the candidate scan of MO:1631 by a proof that the five nearest neighbours are
 among the eight cached ones; nothing observable may change: every iteration's pose, correspondence
@@ -35,13 +36,14 @@ def _same(a, b):
                                           y.view(np.uint8) if y.dtype == np.uint8 else y.view(np.uint32))
 
 
+@pytest.mark.parametrize("pipe", [2, 3])
 @pytest.mark.parametrize("rec", [0, 1, 2, 4, 7])
-def test_split_equals_fused_every_iteration(pkg, oracle, small_case, rec):
+def test_split_equals_fused_every_iteration(pkg, oracle, small_case, rec, pipe):
     for q in small_case["queries"][:2]:
         kw = dict(record_corr_iter=rec, force_all_iters=1, max_iters=9)
         fused = _run(pkg, small_case["map"], q["scan"], q["pose_init"], pipeline=1, **kw)
-        split = _run(pkg, small_case["map"], q["scan"], q["pose_init"], pipeline=2, **kw)
-        assert fused[4].pipeline == 1 and split[4].pipeline == 2
+        split = _run(pkg, small_case["map"], q["scan"], q["pose_init"], pipeline=pipe, **kw)
+        assert fused[4].pipeline == 1 and split[4].pipeline == pipe
         _same(fused, split)
         ocfg = oracle.default_config(knn_mode=1, n_threads=8, force_all_iters=1, max_iters=9)
         _, ro, _, corr = oracle.scan2map(ocfg, q["scan"], small_case["map"], q["pose_init"], corr_iter=rec)
@@ -49,21 +51,24 @@ def test_split_equals_fused_every_iteration(pkg, oracle, small_case, rec):
         np.testing.assert_array_equal(split[3][2], corr[2])
         assert list(ro.n_corr_iter)[:9] == list(split[1].n_corr_iter)[:9]
         # the certificate must actually fire once the pose settles (otherwise this test proves nothing)
-        cert, scanned = np.array(split[4].cert_points[:9]), np.array(split[4].scan_points[:9])
-        assert cert[0] == len(q["scan"]) and 0.9 * cert[0] < scanned[0] <= cert[0]    # (points outside the grid are never scanned)
-        assert scanned[5:9].sum() < 0.25 * cert[5:9].sum(), (cert, scanned)
+        if pipe == 2:
+            cert, scanned = np.array(split[4].cert_points[:9]), np.array(split[4].scan_points[:9])
+            assert cert[0] == len(q["scan"]) and 0.9 * cert[0] < scanned[0] <= cert[0]    # (points outside the grid are never scanned)
+            assert scanned[5:9].sum() < 0.25 * cert[5:9].sum(), (cert, scanned)
 
 
+@pytest.mark.parametrize("pipe", [2, 3])
 @pytest.mark.parametrize("variant", [dict(cell_div=1), dict(cell_div=3, sort_scan=0), dict(sort_scan=2), dict(cell_size=1.7),
                                      dict(jacobian_mode=1), dict(xcd_remap=0)])
-def test_split_variants(pkg, small_case, variant):
+def test_split_variants(pkg, small_case, variant, pipe):
     q = small_case["queries"][2]
     kw = dict(record_corr_iter=3, **variant)
     _same(_run(pkg, small_case["map"], q["scan"], q["pose_init"], pipeline=1, **kw),
-          _run(pkg, small_case["map"], q["scan"], q["pose_init"], pipeline=2, **kw))
+          _run(pkg, small_case["map"], q["scan"], q["pose_init"], pipeline=pipe, **kw))
 
 
-def test_split_on_a_lattice_of_tied_distances(pkg, oracle):
+@pytest.mark.parametrize("pipe", [2, 3])
+def test_split_on_a_lattice_of_tied_distances(pkg, oracle, pipe):
     """Exactly equal distances everywhere (0.5 m lattice, duplicated points, scan points ON map points) while
     the pose creeps by millimetres: the certificate may only fire when no outsider can TIE with the 5th."""
     g = np.arange(0, 8, 0.5, dtype=np.float32)
@@ -76,7 +81,7 @@ def test_split_on_a_lattice_of_tied_distances(pkg, oracle):
     for rec in (0, 1, 3):
         kw = dict(record_corr_iter=rec, force_all_iters=1, max_iters=5)
         fused = _run(pkg, map_xyz, scan, pose0, pipeline=1, **kw)
-        split = _run(pkg, map_xyz, scan, pose0, pipeline=2, **kw)
+        split = _run(pkg, map_xyz, scan, pose0, pipeline=pipe, **kw)
         _same(fused, split)
         ocfg = oracle.default_config(knn_mode=1, n_threads=8, force_all_iters=1, max_iters=5)
         _, ro, _, corr = oracle.scan2map(ocfg, scan, map_xyz, pose0, corr_iter=rec)
@@ -84,8 +89,9 @@ def test_split_on_a_lattice_of_tied_distances(pkg, oracle):
         np.testing.assert_array_equal(split[3][0], corr[0])
 
 
+@pytest.mark.parametrize("pipe", [2, 3])
 @pytest.mark.parametrize("graph_iters", [0, 3, 30])
-def test_split_batches_and_hipgraph(pkg, small_case, graph_iters):
+def test_split_batches_and_hipgraph(pkg, small_case, graph_iters, pipe):
     qs = small_case["queries"]
     scans = [q["scan"] for q in qs] + [qs[0]["scan"][:20], qs[1]["scan"][::2], qs[2]["scan"][:300]]
     poses0 = np.stack([q["pose_init"] for q in qs] + [qs[0]["pose_init"], qs[1]["pose_init"], qs[2]["pose_init"]])
@@ -93,7 +99,7 @@ def test_split_batches_and_hipgraph(pkg, small_case, graph_iters):
     ref.set_map(small_case["map"])
     ref.batch_upload(scans); ref.batch_set_poses(poses0); ref.batch_run()
     pr, rr = ref.batch_results()
-    s = pkg.ScanToMap(pipeline=2, use_graph=1 if graph_iters else 0, graph_iters=max(graph_iters, 1))
+    s = pkg.ScanToMap(pipeline=pipe, use_graph=1 if graph_iters else 0, graph_iters=max(graph_iters, 1))
     s.set_map(small_case["map"])
     for rep in range(2):                       # the second round starts from a warm cache and must not use it
         s.batch_upload(scans) if rep == 0 else None
@@ -113,8 +119,9 @@ def test_split_batches_and_hipgraph(pkg, small_case, graph_iters):
     ref.close(); s.close()
 
 
+@pytest.mark.parametrize("pipe", [2, 3])
 @pytest.mark.parametrize("offset", [(5000.0, -3000.0, 120.0), (-65536.0, 131072.0, 0.0)])
-def test_split_large_coordinates(pkg, offset):
+def test_split_large_coordinates(pkg, offset, pipe):
     """UTM-like offsets (fp32 spacing up to 1.6 cm): the certificate's margins are relative to distances, not
     to coordinates."""
     from test_gpu_fuzz import _planes
@@ -125,4 +132,4 @@ def test_split_large_coordinates(pkg, offset):
                            (map_xyz[::7] - off + rng.normal(0, 0.03, (len(map_xyz[::7]), 3)))]).astype(np.float32)
     pose = np.array([0.01, -0.02, 0.03, off[0] + 0.05, off[1] - 0.04, off[2] + 0.02], np.float32)
     kw = dict(record_corr_iter=4, force_all_iters=1, max_iters=6)
-    _same(_run(pkg, map_xyz, scan, pose, pipeline=1, **kw), _run(pkg, map_xyz, scan, pose, pipeline=2, **kw))
+    _same(_run(pkg, map_xyz, scan, pose, pipeline=1, **kw), _run(pkg, map_xyz, scan, pose, pipeline=pipe, **kw))
