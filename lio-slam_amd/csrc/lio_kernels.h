@@ -47,6 +47,8 @@ struct LioSplitParams {
     float* scan_bound2;            // [total_pts] squared search bound of a pending scan
     int* scan_list;                // [total_pts] per group: slots with a pending scan, longest candidate run first
     int* scan_cnt;                 // [n_groups]
+    float4* plane;                 // [total_pts] k_s2m_iterate_cert: the plane (pa,pb,pc,pd) fitted to cache_idx[0..4] in that order
+    int* plane_state;              // [total_pts] 0 = none, 1 = plane kept and valid (MO:1658-1666), 2 = kept, not valid
     int* stats;                    // [32][n_groups] diagnostics: candidate scans queued by each group in each GN iteration, or null
     int sort_mode;                 // order of a group's work list (see k_s2m_cert)
 };

@@ -380,6 +380,43 @@ LIO_DEV bool lio_assoc_point(const LioIterParams& P, const int nn[5], float qx, 
     return accept;
 }
 
+// The two halves of lio_assoc_point<false> for k_s2m_iterate_cert: the plane through the five neighbours depends on the
+// map points and their ORDER only (MO:1642-1666), not on the scan point's pose, so it can be kept from one Gauss-Newton
+// iteration to the next while the ordered neighbour tuple stays the same; the coefficients (MO:1669-1683) follow the pose.
+LIO_DEV void lio_plane_from_nn(const LioIterParams& P, const int nn[5], float& pa, float& pb, float& pc, float& pd, bool& planeValid)
+{
+    float a[5][3], m[5][3];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float4 mp = P.map_xyz4[nn[j]];
+        m[j][0] = a[j][0] = mp.x;
+        m[j][1] = a[j][1] = mp.y;
+        m[j][2] = a[j][2] = mp.z;
+    }
+    float X0[3];
+    lio_plane_qr5x3(a, X0);                                  // MO:1648
+    pa = X0[0]; pb = X0[1]; pc = X0[2]; pd = 1;               // MO:1650-1653
+    const float ps = sqrtf(pa * pa + pb * pb + pc * pc);      // MO:1655
+    pa /= ps; pb /= ps; pc /= ps; pd /= ps;                   // MO:1656
+    planeValid = true;                                        // MO:1658-1666
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float v = fabsf(pa * m[j][0] + pb * m[j][1] + pc * m[j][2] + pd);
+        if ((double)v > P.c.plane_tol) planeValid = false;
+    }
+}
+
+LIO_DEV bool lio_coeff_from_plane(const LioIterParams& P, float pa, float pb, float pc, float pd, float qx, float qy, float qz,
+                                  float px, float py, float pz, float& cxx, float& cyy, float& czz, float& cww)
+{
+    const float pd2 = pa * qx + pb * qy + pc * qz + pd;   // MO:1669
+    const float r2 = px * px + py * py + pz * pz;
+    // MO:1671-1672 (product, quotient and difference in double)
+    const float s = (float)(1 - P.c.weight * (double)fabsf(pd2) / (double)sqrtf(sqrtf(r2)));
+    cxx = s * pa; cyy = s * pb; czz = s * pc; cww = s * pd2;   // MO:1674-1677
+    return (double)s > P.c.min_s;                         // MO:1679
+}
+
 // (a, b) column pair of each of the 28 sums: 21 upper-triangle JtJ, 6 Jtr, N_c
 static __constant__ int c_pair_a[32] = { 0,0,0,0,0,0, 1,1,1,1,1, 2,2,2,2, 3,3,3, 4,4, 5,  0,1,2,3,4,5, 7, 0,0,0,0 };
 static __constant__ int c_pair_b[32] = { 0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5, 4,5, 5,  6,6,6,6,6,6, 7, 0,0,0,0 };

@@ -124,6 +124,8 @@ struct lio_s2m_handle {
     float* d_scan_bound2 = nullptr; size_t cap_scan_bound2 = 0;
     int* d_scan_list = nullptr; size_t cap_scan_list = 0;
     int* d_scan_cnt = nullptr; size_t cap_scan_cnt = 0;
+    float4* d_plane = nullptr; size_t cap_plane = 0;
+    int* d_plane_state = nullptr; size_t cap_plane_state = 0;
     int* d_split_stats = nullptr; size_t cap_split_stats = 0;      // [32][n_groups]
     // hipGraph-captured chunk of GN iterations (cfg.use_graph)
     hipGraph_t graph = nullptr;
@@ -362,7 +364,7 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
                      h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
                      h->d_nn_cache, h->d_summary, h->d_groups, h->d_cache_idx, h->d_cache_q, h->d_pt_flag,
-                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox, h->d_block_box, h->d_blk_skip };
+                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox, h->d_block_box, h->d_blk_skip, h->d_plane, h->d_plane_state };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < LIO_MAX_ITERS; ++i) {               // (a handle whose creation failed half-way holds nulls)
         if (h->ev_beg[i]) (void)hipEventDestroy(h->ev_beg[i]);
@@ -795,6 +797,10 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         HIPCHK(lio_grow(&h->d_pt_flag, &h->cap_pt_flag, tt));
         HIPCHK(lio_grow(&h->d_scan_bound2, &h->cap_scan_bound2, tt));
         HIPCHK(lio_grow(&h->d_scan_list, &h->cap_scan_list, tt));
+        if (h->certk) {
+            HIPCHK(lio_grow(&h->d_plane, &h->cap_plane, tt));
+            HIPCHK(lio_grow(&h->d_plane_state, &h->cap_plane_state, tt));
+        }
     }
     h->cache_dirty = true;
     const size_t per_blk = (size_t)LIO_BLOCK * ppt;
@@ -1189,6 +1195,8 @@ static void lio_fill_split(lio_s2m_handle* h, const LioIterParams& P, LioSplitPa
     S.scan_bound2 = h->d_scan_bound2;
     S.scan_list = h->d_scan_list;
     S.scan_cnt = h->d_scan_cnt;
+    S.plane = h->d_plane;
+    S.plane_state = h->d_plane_state;
     S.stats = h->cfg.profile ? h->d_split_stats : nullptr;
     const char* sm = getenv("LIO_SPLIT_SORT");
     S.sort_mode = sm ? atoi(sm) : 0;      // measured: 0 (as they come) 246 us, 1 (by run length) 302 us, 2 (per chunk) 249 us for the first scan launch
@@ -1247,6 +1255,7 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     if ((h->split || h->certk) && h->cache_dirty) {
         // 0xff bytes = NaN in the bound word: "no cache" (the `>= 0` test fails)
         HIPCHK(hipMemsetAsync(h->d_cache_q, 0xff, (h->total_pts ? h->total_pts : 1) * sizeof(float4), h->stream));
+        if (h->certk) HIPCHK(hipMemsetAsync(h->d_plane_state, 0, (h->total_pts ? h->total_pts : 1) * sizeof(int), h->stream));
         h->cache_dirty = false;
     }
     // search-bound cache: iteration 0 never reads it and rewrites the entry of every point it processes; entries
