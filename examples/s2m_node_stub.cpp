@@ -46,6 +46,30 @@ int main(int argc, char** argv)
                     s2m.last.converged, (int)s2m.isDegenerate, s2m.last.n_corr_last, s2m.transformTobeMapped[0],
                     s2m.transformTobeMapped[1], s2m.transformTobeMapped[2], s2m.transformTobeMapped[3],
                     s2m.transformTobeMapped[4], s2m.transformTobeMapped[5]);
+
+        // ---- variant (a) of INTEGRATION.md: the same registration straight from the PointCloud2 blob of
+        //      msgIn->cloud_deskewed (MO:440, cloud_info.msg:27): data pointer, width*height, point_step, offset of "x"
+        liogpu::ScanToMap pc2;
+        for (int k = 0; k < 6; ++k) pc2.transformTobeMapped[k] = std::strtof(argv[3 + k], nullptr);
+        pc2.setInputCloud(laserCloudSurfFromMapDS.data(), laserCloudSurfFromMapDS.size(), sizeof(PointXYZI));
+        pc2.scan2MapOptimizationPC2(laserCloudSurfLastDS.data(), laserCloudSurfLastDS.size(), (uint32_t)sizeof(PointXYZI), 0, true);
+        pc2.transformUpdate(false, 0, 0.0f, 0.0f, 0.01f, 1000.0f, 1000.0f);
+        std::printf("pc2 iters %d pose %.9g %.9g %.9g %.9g %.9g %.9g\n", pc2.last.iters, pc2.transformTobeMapped[0],
+                    pc2.transformTobeMapped[1], pc2.transformTobeMapped[2], pc2.transformTobeMapped[3],
+                    pc2.transformTobeMapped[4], pc2.transformTobeMapped[5]);
+
+        // ---- variant (b): several GPUs behind the same calls (here the one device listed twice)
+        lio_s2m_config cfg;
+        lio_s2m_default_config(&cfg);
+        cfg.n_devices = 2; cfg.device_ids[0] = 0; cfg.device_ids[1] = 0;
+        liogpu::ScanToMap multi(&cfg);
+        for (int k = 0; k < 6; ++k) multi.transformTobeMapped[k] = std::strtof(argv[3 + k], nullptr);
+        multi.setInputCloud(laserCloudSurfFromMapDS.data(), laserCloudSurfFromMapDS.size(), sizeof(PointXYZI));
+        multi.scan2MapOptimization(laserCloudSurfLastDS.data(), laserCloudSurfLastDS.size(), sizeof(PointXYZI));
+        multi.transformUpdate(false, 0, 0.0f, 0.0f, 0.01f, 1000.0f, 1000.0f);
+        std::printf("multi iters %d pose %.9g %.9g %.9g %.9g %.9g %.9g\n", multi.last.iters, multi.transformTobeMapped[0],
+                    multi.transformTobeMapped[1], multi.transformTobeMapped[2], multi.transformTobeMapped[3],
+                    multi.transformTobeMapped[4], multi.transformTobeMapped[5]);
     } catch (const liogpu::Error& e) {
         // hard errors (<0): the node falls back to its own CPU loop MO:1846-1859
         std::fprintf(stderr, "liogpu: %s (code %d)\n", e.what(), e.code);

@@ -32,3 +32,12 @@ def test_cpp_node_stub_matches_python_path(pkg, tmp_path):
     np.testing.assert_array_equal(pose_cpp, pose_py)
     np.testing.assert_allclose(pose_cpp[3:], g["pose"][3:], atol=1e-5)
     s2m.close()
+    # the PointCloud2 entry point and the multi-device handle behind the same C++ members
+    lines = out.strip().split("\n")
+    pc2 = lines[1].split()
+    assert pc2[0] == "pc2" and int(pc2[2]) == int(g["iters"])
+    np.testing.assert_array_equal(np.array([float(v) for v in pc2[4:10]], np.float32), pose_py)
+    mu = lines[2].split()
+    assert mu[0] == "multi" and int(mu[2]) == int(g["iters"])
+    pm = np.array([float(v) for v in mu[4:10]], np.float32)
+    assert np.abs(pm[3:] - pose_py[3:]).max() <= 1e-5 and np.abs(pm[:3] - pose_py[:3]).max() <= 1e-6
