@@ -224,7 +224,7 @@ LIO_DEV void lio_nbr_store(float* __restrict__ base, int pos, float x, float y, 
     p[0] = x; p[2] = y; p[4] = z; p[6] = w;
 }
 
-// Every (y,z) row list is padded to a multiple of four records (the pad goes to its last cell and
+// Every (y,z) row list is padded to a multiple of LIO_ROW_ALIGN (eight) records (the pad goes to its last cell and
 // stays filled with dummies), so row lists start 4-aligned and an aligned group of four never
 // straddles two row lists -- neighbouring rows hold copies of the same map points, and a candidate
 // seen twice would corrupt the top-5.
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_map_nbr_pad_rows(LioGrid g, int* __rest
     for (int x = lane; x < g.nx; x += 64) s += nbr_count[row * g.nx + x];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) nbr_count[row * g.nx + g.nx - 1] += (4 - (s & 3)) & 3;
+    if (lane == 0) nbr_count[row * g.nx + g.nx - 1] += (LIO_ROW_ALIGN - (s & (LIO_ROW_ALIGN - 1))) & (LIO_ROW_ALIGN - 1);
 }
 
 __global__ void k_map_nbr_fill(float4* __restrict__ nbr_pts, int n_rec4)
@@ -1126,7 +1126,7 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
     lio_launch_exclusive_scan(cell_count, g.n_cells, tile_sums, nbr_start, s);
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);
     {
-        const int n_rec4 = n * (2 * g.k + 1) * (2 * g.k + 1) + 4 * g.ny * g.nz + 8;   // + row and tail padding
+        const int n_rec4 = n * (2 * g.k + 1) * (2 * g.k + 1) + LIO_ROW_ALIGN * g.ny * g.nz + 2 * LIO_ROW_ALIGN;   // + row and tail padding
         hipLaunchKernelGGL(k_map_nbr_fill, dim3((n_rec4 + 255) / 256), dim3(256), 0, s, nbr_pts, n_rec4);
     }
     hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, nbr_start, cell_count, nbr_pts);

@@ -251,7 +251,11 @@ LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, 
     const int x0 = max(max(cx - g.k, 0), xlo), x1 = min(min(cx + g.k, g.nx - 1), xhi);
     if (x0 > x1) return;
     const int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nx;
+#if LIO_PREFETCH == 3
+    const unsigned beg = (unsigned)P.nbr_start[row + x0] & ~7u;
+#else
     const unsigned beg = (unsigned)P.nbr_start[row + x0] & ~3u;
+#endif
     const unsigned end = (unsigned)P.nbr_start[row + x1 + 1];
     if (beg >= end) return;
     const lio_f2 QX = { qx, qx }, QY = { qy, qy }, QZ = { qz, qz };
@@ -276,6 +280,21 @@ LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, 
         const float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
         lio_knn_group(c0, c1, c2, c3, QX, QY, QZ, top);
     }
+#elif LIO_PREFETCH == 3
+    // Two groups per trip with a single exit at the bottom (`beg` is aligned down to eight records for this; row lists are
+    // padded to eight, so the extra group still belongs to the same row list): group b is loaded while a is evaluated
+    // and the next trip's a while b is, each into its own registers -- no rotation copies (8 of the 57 vector
+    // instructions of the rotating form were v_mov_b64).  Costs up to one extra group per point.
+    float4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+    unsigned j = beg;
+    do {
+        const float4 b0 = p[4], b1 = p[5], b2 = p[6], b3 = p[7];
+        lio_knn_group(a0, a1, a2, a3, QX, QY, QZ, top);
+        p += 8;
+        a0 = p[0]; a1 = p[1]; a2 = p[2]; a3 = p[3];            // (reads past the run at the last trip: the table is padded)
+        lio_knn_group(b0, b1, b2, b3, QX, QY, QZ, top);
+        j += 8;
+    } while (j < end);
 #else
     float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
     for (unsigned j = beg + 4; j < end; j += 4) {

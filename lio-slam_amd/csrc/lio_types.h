@@ -7,6 +7,7 @@
 #define LIO_SUMS 32          // per-scan sums: 21 upper JtJ + 6 Jtr + N_c + pad to 32 doubles
 #define LIO_SUM_NC 27
 #define LIO_BLOCK 256        // threads per association workgroup (4 waves)
+#define LIO_ROW_ALIGN 8      // records: every neighbourhood row list starts at a multiple of this and is padded to one
 
 // Hash grid over the voxel-downsampled local map (laserCloudSurfFromMapDS,
 // MO:149).  cell(v) = floor((v - origin) * inv_cell), linear id x-fastest so
