@@ -132,3 +132,34 @@ def test_plan_shards_properties():
         assert max(counts) < 2.0 * len(pts) / world + 500           # balanced slabs
     empty = mg.plan_shards(np.zeros((0, 3), np.float32), 4)
     assert len(mg.shard_points(np.zeros((0, 3), np.float32), empty, 2)) == 0
+
+
+def test_slab_plan_properties():
+    """Host logic of the sharded map (lio-slam_amd/multigpu.py): bounds are monotone and cover the grid, a plan balanced by
+    a load sample equalises that sample (not the map), a wider halo only ever adds map points, and every map point is held
+    by the rank that owns its cell."""
+    mg = importlib.import_module("lio-slam_amd.multigpu")
+    rng = np.random.default_rng(5)
+    # a long map with uniform density, and a "scan load" concentrated in its middle
+    map_xyz = np.stack([rng.uniform(0, 300, 60000), rng.uniform(-10, 10, 60000), rng.uniform(0, 5, 60000)], 1).astype(np.float32)
+    load = np.stack([rng.normal(150, 25, 40000), rng.uniform(-10, 10, 40000), rng.uniform(0, 5, 40000)], 1).astype(np.float32)
+    for world in (2, 4, 8):
+        p_map = mg.plan_shards(map_xyz, world)
+        p_load = mg.plan_shards(map_xyz, world, load_xyz=load)
+        for plan, sample in ((p_map, map_xyz), (p_load, load)):
+            b = plan["bounds"]
+            assert b[0] == 0 and b[-1] == plan["dims"][plan["axis"]] and np.all(np.diff(b) >= 0) and plan["axis"] == 0
+            c = np.clip(mg.cell_coord(sample[:, 0], plan["origin"][0], plan["inv_cell"], plan["dims"][0]), 0, plan["dims"][0] - 1)
+            share = np.array([((c >= b[r]) & (c < b[r + 1])).sum() for r in range(world)]) / len(sample)
+            assert share.max() < 1.0 / world + 0.03, (world, share)           # balanced by what it was planned from
+        # the load-balanced slabs are narrow where the load is and wide at the ends
+        if world > 2:                                                          # (two symmetric halves are the same either way)
+            assert np.diff(p_load["bounds"]).min() < np.diff(p_map["bounds"]).min()
+        for rank in range(world):
+            i1 = mg.shard_points(map_xyz, p_load, rank, 1)
+            i16 = mg.shard_points(map_xyz, p_load, rank, 16)
+            assert set(i1.tolist()) <= set(i16.tolist()) and len(i16) >= len(i1)
+            own = mg.owner_mask(map_xyz, p_load, rank)
+            assert own[i1].sum() == own.sum()                                  # every owned point is in the held set
+    # the plan cell follows the gate radius (the device-side owner test derives its cell from the same fields)
+    assert abs(float(mg.default_cell(0.49)) - 0.7 * 1.001) < 1e-6
