@@ -706,17 +706,17 @@ __global__ void k_s2m_init_state(LioScanState* __restrict__ st, int n_scans,
 // region are contiguous runs), s_cell the run offsets of every cell of the
 // region: rx+1 entries per (y,z) row.
 LIO_DEV void lio_knn_lds(const float4* s_pts, const int* s_cell, int rx1, int ry,
-                         int rx0, int ry0, int rz0, int ry1, int rz1, int nx,
+                         int rx0, int ry0, int rz0, int ry1, int rz1, int nx, int k,
                          float qx, float qy, float qz, int cx, int cy, int cz, LioTop5& top)
 {
-    const int xa = max(cx - 1, 0), xb = min(cx + 1, nx - 1);
+    const int xa = max(cx - k, 0), xb = min(cx + k, nx - 1);
     if (xa > xb) return;
 #pragma unroll 1
-    for (int dz = -1; dz <= 1; ++dz) {
+    for (int dz = -k; dz <= k; ++dz) {
         const int z = cz + dz;
         if (z < rz0 || z > rz1) continue;
 #pragma unroll 1
-        for (int dy = -1; dy <= 1; ++dy) {
+        for (int dy = -k; dy <= k; ++dy) {
             const int y = cy + dy;
             if (y < ry0 || y > ry1) continue;
             const int r = (z - rz0) * ry + (y - ry0);
@@ -736,8 +736,8 @@ LIO_DEV void lio_knn_lds(const float4* s_pts, const int* s_cell, int rx1, int ry
                              // measured: 4 -> 5 is -6 % time, 6 spills and is 20 % slower); the other instantiations keep 4
 #endif
 #define LIO_LDS_PTS   2048     // staged map points per workgroup (32 KiB)
-#define LIO_LDS_CELLS 1536     // staged run offsets (6 KiB)
-#define LIO_LDS_ROWS  256      // (y,z) rows of a region
+#define LIO_LDS_CELLS 4096     // staged run offsets (16 KiB)
+#define LIO_LDS_ROWS  256      // (y,z) rows of a region (one thread each)
 
 // One thread = one scan point (x PPT points, strided by the workgroup size).
 // STAGE: the workgroup's points are spatially sorted at upload, so their
@@ -875,9 +875,9 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
             for (int a = 0; a < 3; ++a) { atomicMin(&s_box[a], bmn[a]); atomicMax(&s_box[3 + a], bmx[a]); }
         }
         __syncthreads();
-        rx0 = max(s_box[0] - 1, 0); rx1c = min(s_box[3] + 1, g.nx - 1);
-        ry0 = max(s_box[1] - 1, 0); ry1 = min(s_box[4] + 1, g.ny - 1);
-        rz0 = max(s_box[2] - 1, 0); rz1 = min(s_box[5] + 1, g.nz - 1);
+        rx0 = max(s_box[0] - g.k, 0); rx1c = min(s_box[3] + g.k, g.nx - 1);
+        ry0 = max(s_box[1] - g.k, 0); ry1 = min(s_box[4] + g.k, g.ny - 1);
+        rz0 = max(s_box[2] - g.k, 0); rz1 = min(s_box[5] + g.k, g.nz - 1);
         const bool any = s_box[0] != 0x7fffffff && rx0 <= rx1c && ry0 <= ry1 && rz0 <= rz1;
         rxn1 = rx1c - rx0 + 2;                      // run offsets per row (cells + 1)
         ryn = ry1 - ry0 + 1;
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
         LioTop5 top = { sentinel, sentinel, sentinel, sentinel, sentinel };
         if (act[pp]) {
             if (STAGE && staged)
-                lio_knn_lds(s_pts, s_cell, rxn1, ryn, rx0, ry0, rz0, ry1, rz1, g.nx,
+                lio_knn_lds(s_pts, s_cell, rxn1, ryn, rx0, ry0, rz0, ry1, rz1, g.nx, g.k,
                             qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], top);
             else
                 lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], xlo, xhi, top);

@@ -437,7 +437,6 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
     // cell edge = gate radius (+0.1 %) / k; the candidate scan visits (2k+1)^3 cells
     int kdiv = h->cfg.cell_div;
     if (kdiv != 1 && kdiv != 2 && kdiv != 3) kdiv = 2;
-    if (h->cfg.use_lds) kdiv = 1;                      // the LDS-staged variant assumes a one-cell halo
     float cell = (h->cfg.cell_size > 0.0f ? h->cfg.cell_size : sqrtf(h->cfg.max_sq_dist) * 1.001f) / (float)kdiv;
     LioGrid g;
     for (;;) {
