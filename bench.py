@@ -7,8 +7,10 @@ boundary: the raw pcl::PointXYZI records of the batch (resident in HBM when the 
 staged, tile-sorted into the SoA layout, every scan gets its own initial guess and runs the Gauss-Newton
 loop (<= 30 iterations, each scan stops at its own convergence, MO:1848-1859), and the B results are read
 back.  Every step registers a DIFFERENT batch (`--batches` distinct batches are cycled); two handles
-sharing the resident map form a double buffer, so the staging + sort of batch k+1 overlaps the GN loop of
-batch k.  Also reported, never as `value`: the same stream with the records coming from pinned HOST memory
+sharing the resident map form a double buffer: batch k+1 is staged, sorted and STARTED while batch k still
+iterates, and only then are the results of batch k collected.  The roofline of the dominant kernel is measured
+in the same run by a separate pass in which the kernel has the GPU to itself (`--roofline-pass-only` makes
+that pass the only timed region, for rocprofv3).  Also reported, never as `value`: the same stream with the records coming from pinned HOST memory
 over PCIe (`streamed_h2d`), the GN loop alone on a pre-sorted resident batch (`gn_loop_only`, round 1's
 definition), and the single-scan sequence a patched node issues per callback (`single_scan_node_path_ms`).
 
@@ -160,6 +162,8 @@ def main():
                     help="N>1: map = slabs of the map + halo, owner-computes (north_star); scan = map replicated, workgroups of every scan dealt round-robin")
     ap.add_argument("--nncache", type=int, default=1, help="1 = bound each point's search by its previous neighbours (exact)")
     ap.add_argument("--pipeline", type=int, default=0, help="0/1 = fused k_s2m_iterate, 2 = split cert/scan/fit (A/B only)")
+    ap.add_argument("--roofline-pass-only", action="store_true", help="profiling: make the roofline pass (GN loop alone on one "
+                    "pre-sorted resident batch, launches of k_s2m_iterate never overlapping anything) the ONLY timed region")
     ap.add_argument("--single-buffer", action="store_true", help="A/B: one handle, no overlap of staging and GN loop")
     ap.add_argument("--maxsq", type=float, default=1.0, help="DIAGNOSTIC: squared 5-NN gate (reference: 1.0); smaller values shrink the "
                     "searched neighbourhood and change the results -- only for timing what-if runs")
@@ -336,48 +340,57 @@ def main():
             handles.append(hB)
 
         def run_stream(n_steps, sources, first_batch=0, keep=None):
-            """Software pipeline over the handles: GN loop of batch k (asynchronous) || staging + tile sort of batch
-            k+1 on the other handle's stream, then the results of batch k."""
+            """Software pipeline over the handles: while batch k iterates (asynchronous launch loop on its handle's stream),
+            batch k+1 is staged, tile-sorted and STARTED on the other handle's stream -- its first, large launches overlap
+            the last, nearly empty ones of batch k -- and only then are the results of batch k collected."""
             nh = len(handles)
             ptr = lambda b: sources[b].data_ptr() if hasattr(sources[b], "data_ptr") else sources[b].ptr
-            handles[0].batch_upload_raw(ptr(first_batch % NB), batch_npts[first_batch % NB], stride)
+
+            def start(k):
+                b = (first_batch + k) % NB
+                h = handles[k % nh]
+                h.batch_upload_raw(ptr(b), batch_npts[b], stride)
+                h.batch_set_poses(poses0[b * B:(b + 1) * B])
+                h.batch_run()
+
             out = None
+            if nh > 1:
+                start(0)
             for k in range(n_steps):
                 b = (first_batch + k) % NB
                 h = handles[k % nh]
-                h.batch_set_poses(poses0[b * B:(b + 1) * B])
-                h.batch_run()
-                if nh > 1 and k + 1 < n_steps:
-                    nb_ = (b + 1) % NB
-                    handles[(k + 1) % nh].batch_upload_raw(ptr(nb_), batch_npts[nb_], stride)
+                if nh == 1:
+                    start(k)
+                elif k + 1 < n_steps:
+                    start(k + 1)
                 out = h.batch_results(with_results=False)[0]
                 if keep is not None:                      # launch accounting of EVERY timed step (HIP events on h's stream)
                     pr = h.profile()
                     keep.setdefault("unit_ms", []).extend(pr.launch_ms[:pr.n_units])
                     keep["launches"] = keep.get("launches", 0) + pr.n_units * max(pr.unit_iters, 1)
                     keep["point_iters"] = keep.get("point_iters", 0) + int(pr.point_iters)
-                if nh == 1 and k + 1 < n_steps:
-                    nb_ = (b + 1) % NB
-                    h.batch_upload_raw(ptr(nb_), batch_npts[nb_], stride)
                 if keep is not None and b == 0:
                     keep["poses"] = out
             return out
 
     keep = {}
-    run_stream(args.warmup, dev_rec, keep=keep)
-    sync_all()
-    for k_ in ("unit_ms", "launches", "point_iters"):      # (accounting restarts with the timed region)
-        keep.pop(k_, None)
-    t0 = time.perf_counter()
-    run_stream(args.steps, dev_rec, first_batch=args.warmup, keep=keep)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    value = B * args.steps / elapsed
-    last_b = (args.warmup + args.steps - 1) % NB          # the batch of the last timed step
+    if not (args.roofline_pass_only and not sharded):
+        run_stream(args.warmup, dev_rec, keep=keep)
+        sync_all()
+        for k_ in ("unit_ms", "launches", "point_iters"):      # (accounting restarts with the timed region)
+            keep.pop(k_, None)
+        t0 = time.perf_counter()
+        run_stream(args.steps, dev_rec, first_batch=args.warmup, keep=keep)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+    streamed_acct = {k_: keep.get(k_) for k_ in ("unit_ms", "launches", "point_iters")}
+
+    value = B * args.steps / elapsed if not (args.roofline_pass_only and not sharded) else 0.0
+    last_b = 0 if (args.roofline_pass_only and not sharded) else (args.warmup + args.steps - 1) % NB   # the batch of the last timed step
 
     # per-launch accounting of the dominant kernel from the LAST timed step (HIP events on the handle's stream)
     ns_last = n_s[last_b * B:(last_b + 1) * B]
@@ -395,6 +408,9 @@ def main():
         prof = None
     else:
         h_last = handles[(args.steps - 1) % len(handles)]
+        if args.roofline_pass_only:                   # (profiling run: the streamed region was skipped; one plain batch for the trace)
+            h_last = handles[0]
+            h_last.batch_upload(batch_scans[0]); h_last.batch_set_poses(poses0[:B]); h_last.batch_run()
         poses_last, results = h_last.batch_results(with_results=True)
         prof = h_last.profile()
         iters = np.array([r.iters for r in results])
@@ -406,13 +422,55 @@ def main():
         unit_ms = np.array(prof.launch_ms[:prof.n_units], dtype=np.float64)
         lms = np.repeat(unit_ms / ui, ui)
         pts_per_launch = np.array([int(ns_last[iters > i].sum()) for i in range(n_launch)], dtype=np.float64)
+    # Roofline pass (single GPU): the dominant kernel ALONE on the GPU.  In the streamed region the launch loops of two
+    # batches overlap on purpose (that is what hides the tails), so the duration of a launch there measures how the
+    # GPU is shared, not the kernel.  Here one pre-sorted resident batch is re-registered from its initial poses with
+    # nothing else in flight, and every launch of every step is bracketed by HIP events on the handle's stream.
+    roof = None
+    if not sharded:
+        g = handles[0]
+        g.batch_upload(batch_scans[0])
+        n_roof = args.steps if args.roofline_pass_only else 32
+
+        def gn_step(acct=None):
+            g.batch_set_poses(poses0[:B])
+            g.batch_run()
+            p_ = g.batch_results(with_results=False)[0]
+            if acct is not None:
+                pr = g.profile()
+                acct["unit_ms"].extend(pr.launch_ms[:pr.n_units])
+                acct["launches"] += pr.n_units * max(pr.unit_iters, 1)
+                acct["point_iters"] += int(pr.point_iters)
+            return p_
+
+        for _ in range(max(3, args.warmup if args.roofline_pass_only else 3)):
+            gn_step()
+        sync_all()
+        roof = {"unit_ms": [], "launches": 0, "point_iters": 0}
+        t0 = time.perf_counter()
+        for _ in range(n_roof):
+            p_roof = gn_step(roof)
+        sync_all()
+        roof["elapsed"] = time.perf_counter() - t0
+        roof["steps"] = n_roof
+        if args.roofline_pass_only:
+            elapsed = roof["elapsed"]
+            value = B * args.steps / elapsed
+            keep["poses"] = p_roof
     live = lms > 0
-    if runner is None and keep.get("launches"):
-        # single GPU: averages over ALL launches of ALL timed steps (what rocprofv3's kernel statistics average too)
-        tot_ms = float(np.sum(keep["unit_ms"]))
-        ms_per_launch = tot_ms / keep["launches"]
-        bytes_per_launch = BYTES_PER_POINT_ITER * keep["point_iters"] / keep["launches"]
-        achieved = BYTES_PER_POINT_ITER * keep["point_iters"] / (tot_ms * 1e-3) / 1e9
+    in_stream = None
+    if roof is not None and roof["launches"]:
+        # single GPU: averages over ALL launches of ALL steps of the roofline pass (what rocprofv3's kernel statistics
+        # average too when the same pass is traced: `--roofline-pass-only`)
+        tot_ms = float(np.sum(roof["unit_ms"]))
+        ms_per_launch = tot_ms / roof["launches"]
+        bytes_per_launch = BYTES_PER_POINT_ITER * roof["point_iters"] / roof["launches"]
+        achieved = BYTES_PER_POINT_ITER * roof["point_iters"] / (tot_ms * 1e-3) / 1e9
+        if streamed_acct.get("launches"):
+            in_stream = {"ms_per_launch_while_two_batches_overlap": float(np.sum(streamed_acct["unit_ms"])) / streamed_acct["launches"],
+                         "launches": int(streamed_acct["launches"]),
+                         "algorithmic_GBs_of_the_whole_pipeline": BYTES_PER_POINT_ITER * streamed_acct["point_iters"] / elapsed / 1e9,
+                         "note": "72 B x every live point-iteration of the timed region / its wall time (staging and tile sort included)"}
     else:
         bytes_per_launch = BYTES_PER_POINT_ITER * pts_per_launch[live].mean() if live.any() else 0.0
         ms_per_launch = float(lms[live].mean()) if live.any() else float("nan")
@@ -435,7 +493,8 @@ def main():
             "workload": f"{args.sensor} {synth.SENSORS[args.sensor][0]}x{synth.SENSORS[args.sensor][1]} synthetic street-canyon "
                         f"scans vs {args.keyframes}-keyframe map (BASELINE.json headline = hdl64 64x1800 vs 200; "
                         f"configs[4] batched form), {NB} distinct batches streamed",
-            "timed_region": "per step, for a batch not seen in the previous step: staging of the raw records (resident in HBM) + AoS->SoA + "
+            "timed_region": "ROOFLINE PASS ONLY (profiling run): GN loop of one pre-sorted resident batch" if (args.roofline_pass_only and not sharded) else
+                            "per step, for a batch not seen in the previous step: staging of the raw records (resident in HBM) + AoS->SoA + "
                             "tile sort, B initial poses in, whole GN loop, B results out" + ("" if sharded else
                             "; double-buffered over two handles sharing the map" if len(handles) > 1 else "; single handle"),
             "inputs_resident_in_hbm": True, "h2d_in_timed_region": False, "input_record_bytes": stride,
@@ -456,11 +515,13 @@ def main():
                        "scan is ~40 % and the bit-exact plane fit ~40 %) with the divergent candidate gathers keeping the texture "
                        "addresser ~75 % busy; see DESIGN.md section 6",
             "launches_per_step": int(live.sum()), "launches_per_graph_replay": int(args.graph), "algorithmic_bytes_per_launch": bytes_per_launch,
-            "launches_measured": int(keep.get("launches", live.sum())),
+            "launches_measured": int(roof["launches"]) if roof else int(live.sum()),
+            "in_streamed_region": in_stream,
             "last_step_launch_ms": [round(float(v), 4) for v in lms], "last_step_launch_points": [int(v) for v in pts_per_launch],
-            "measured": "HIP events around every graph replay of every timed step on the handle's own stream (the other handle's "
-                        "staging/sort kernels run concurrently and stretch the launches they overlap); algorithmic bytes = 72 B x "
-                        "live point-iterations of the same steps",
+            "measured": "roofline pass of this run: one pre-sorted resident batch re-registered with nothing else in flight, HIP events "
+                        "around every graph replay of every step on the handle's stream; algorithmic bytes = 72 B x live point-iterations "
+                        "of the same steps.  (In the streamed region two batches' launch loops overlap on purpose, see in_streamed_region.)"
+                        if not sharded else "HIP events around the launches of the last timed step",
         },
         "map_build_ms": prof0.map_build_ms, "map_upload_ms": prof0.map_upload_ms,
         "grid_cells": int(prof0.n_cells),
@@ -492,25 +553,9 @@ def main():
                                        f"{stride}-byte records; upload of batch k+1 overlaps the GN loop of batch k"}
         for p in pins:
             p.close()
-        # (2) round 1's definition: GN loop only, one pre-sorted resident batch re-registered from its initial poses
-        g = handles[0]
-        g.batch_upload(batch_scans[0])
-
-        def gn_step():
-            g.batch_set_poses(poses0[:B])
-            g.batch_run()
-            return g.batch_results(with_results=False)[0]
-
-        for _ in range(3):
-            gn_step()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(32):
-            gn_step()
-        sync_all()
-        el = time.perf_counter() - t0
-        out["gn_loop_only"] = {"value": B * 32 / el, "unit": "registrations/s", "ms_per_step": 1e3 * el / 32,
-                               "note": "inputs uploaded and tile-sorted once outside the timer (round 1's `value`)"}
+    if roof is not None:
+        out["gn_loop_only"] = {"value": B * roof["steps"] / roof["elapsed"], "unit": "registrations/s", "ms_per_step": 1e3 * roof["elapsed"] / roof["steps"],
+                               "note": "the roofline pass: inputs uploaded and tile-sorted once outside the timer (round 1's `value`)"}
 
     # N > 1 only: the same registrations with NO collective -- every rank registers its own share of the batch
     # against the replicated map through the single-GPU path.  Registrations are independent objects, so this is

@@ -11,7 +11,7 @@ CASE=/tmp/case8.npz
 python bench.py --steps 1 --warmup 1 --no-cpu --no-extras --case-cache $CASE > /dev/null 2> $OUT/gen.log   # writes the case cache
 # the same timed workload as the default `python bench.py` (8 distinct batches streamed, double-buffered), without the CPU
 # baseline and the secondary measurements, which would mix other launches of the same kernels into the averages
-B="python bench.py --steps 16 --warmup 4 --no-cpu --no-extras --case-cache $CASE"
+B="python bench.py --steps 16 --warmup 4 --no-cpu --no-extras --roofline-pass-only --case-cache $CASE"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/kt -o runc -- $B > $OUT/bench_under_rocprof.json 2> /tmp/kt.err
 python tools/prof_summary.py /tmp/prof/kt k_ > $OUT/rocprofv3_kernel_stats.txt
 pass() { # name, counters...
