@@ -163,3 +163,29 @@ def test_one_launch_lds_sort_equals_the_counting_sort(pkg, small_case):
             np.testing.assert_array_equal(u, v)
         for u, v in zip(a[4], b[4]):
             np.testing.assert_array_equal(u, v)
+
+
+def test_lds_sort_size_boundaries(pkg, small_case):
+    """The one-launch LDS sort takes scans of up to 16384 points (power-of-two padding, 64 KiB of keys); one point more and
+    the batch goes through the multi-kernel counting sort.  Same results on both sides of every boundary."""
+    rng = np.random.default_rng(9)
+    m = small_case["map"]
+    base = small_case["queries"][0]
+    pose0 = base["pose_init"]
+    big = m[rng.integers(0, len(m), 20000)] + rng.normal(0, 0.03, (20000, 3)).astype(np.float32)    # map-like points, world frame
+    T = np.eye(4)
+    for n in (1, 63, 64, 65, 4096, 4097, 8192, 8193, 16383, 16384, 16385):
+        scan = np.ascontiguousarray(big[:n], np.float32)
+        zero = np.zeros(6, np.float32)
+        outs = []
+        for mode in (2, 3):
+            s = pkg.ScanToMap(sort_scan=mode, max_iters=3, force_all_iters=1)
+            s.set_map(m)
+            s.batch_upload([scan, base["scan"]]); s.batch_set_poses(np.stack([zero, pose0])); s.batch_run()
+            p, r = s.batch_results()
+            outs.append((p, [np.array(x.AtA, np.float32).view(np.uint32) for x in r], [x.n_corr_last for x in r]))
+            s.close()
+        np.testing.assert_array_equal(outs[0][0], outs[1][0])
+        for a, b in zip(outs[0][1], outs[1][1]):
+            np.testing.assert_array_equal(a, b)
+        assert outs[0][2] == outs[1][2], n
