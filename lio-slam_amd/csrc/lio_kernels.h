@@ -65,6 +65,7 @@ void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, co
 void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s, bool corner = false);
 void lio_launch_split_iteration(const LioSplitParams& S, int n_blocks, hipStream_t s);
 void lio_launch_iterate_cert(const LioSplitParams& S, int n_blocks, hipStream_t s);
+void lio_launch_persist(const LioIterParams& P, int n_blocks, unsigned* gen, int n_scans, int* fault, hipStream_t s);
 void lio_launch_pack_summary(const LioScanState* st, int n_scans, float* out, hipStream_t s);
 void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
                       int* n_active, hipStream_t s);

@@ -1,0 +1,195 @@
+// lio_persist.hip -- k_s2m_persist: the whole Gauss-Newton loop of scan2MapOptimization (MO:1848-1859) in ONE launch
+// (cfg.pipeline = 4), for batches whose association workgroups are all resident at once (a single registration is
+// ~26 workgroups on 256 CUs).  Same results as the launch loop of k_s2m_iterate, bit for bit: the per-iteration body is
+// the same arithmetic in the same order (phase A transform + cells, bounded exact 5-NN, lio_assoc_point, Jacobian row,
+// LDS-transposed fp64 sums, write-through partials, arrival counter, solve by the last workgroup of the scan).
+//
+// What replaces the kernel boundary between two iterations is a PER-SCAN barrier, not a grid-wide one: the workgroups
+// of scan s only wait for scan s's solve.  The solving wave re-arms the arrival counter, releases (agent scope: its
+// XCD's L2 is written back) and publishes gen[s] = iterations done; wave 0 of every other workgroup of the scan polls
+// gen[s] with write-through loads, then the whole workgroup acquires (L1 / non-local L2 lines invalidated) and re-reads
+// the scan's state.  Every poll loop is bounded: after LIO_PERSIST_SPIN_MAX polls the workgroup raises *fault and
+// leaves, so every wave reaches an exit whatever happens (the host then reports LIO_ERR_HIP).
+#include <hip/hip_runtime.h>
+#include "lio_kernels.h"
+#include "lio_device_math.h"
+#include "lio_s2m_device.h"
+
+#define LIO_PERSIST_SPIN_MAX (1u << 19)      // ~1 s of polling (a poll is a sleep + one L2-bypassing load)
+
+namespace {
+
+__global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, unsigned* __restrict__ gen, int* __restrict__ fault)
+{
+    __shared__ __attribute__((aligned(16))) double s_rows[LIO_BLOCK][8];
+    __shared__ double s_part[8][28];
+    __shared__ double s_sum[28];
+    __shared__ LioSolveWs s_ws;
+    __shared__ int s_ctl;                                  // 0 = next iteration, 1 = the scan is done, 2 = poll timed out
+
+    const int wg = blockIdx.x;                             // (no XCD remap: a registration's few workgroups are spread over the XCDs as dealt)
+    const LioBlockDesc bd = P.blocks[wg];
+    LioScanState* st = &P.state[bd.scan];
+    const LioGrid g = P.grid;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_pts = st->n_pts, base = st->offset;
+    const int li = bd.first + (int)threadIdx.x;
+    const bool inr = li < n_pts;
+    const int gi = base + (inr ? li : 0);
+    const float px = P.sx[gi], py = P.sy[gi], pz = P.sz[gi];             // the scan point never changes: loaded once
+    const int ci = base + bd.first + (int)threadIdx.x;                   // slot in the batch SoA
+    const int red_g = threadIdx.x >> 5, red_s = threadIdx.x & 31;
+    const int red_a = c_pair_a[red_s], red_b = c_pair_b[red_s];
+    if (st->done) return;                                                // (too few points: k_s2m_init_state) workgroup-uniform
+
+#pragma unroll 1
+    for (int it = 0;; ++it) {
+        // per-scan values of this iteration (fresh: kernel start, or acquired at the bottom of the previous trip)
+        float T[12], tr[6], Tp[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T[k] = st->T[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) tr[k] = st->trig[k];
+        const int st_iter = st->iter;
+        const bool record = (P.rec_flag != nullptr) && (st_iter == P.c.record_iter);
+        const bool use_cache = (P.d5_cache != nullptr) && st_iter > 0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Tp[k] = use_cache ? st->Tp[k] : 0.0f;
+
+        // ---- phase A: pointAssociateToMap MO:841-847, cells
+        const float qx = T[0] * px + T[1] * py + T[2]  * pz + T[3];
+        const float qy = T[4] * px + T[5] * py + T[6]  * pz + T[7];
+        const float qz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+        const int cx = lio_cell_coord(qx, g.ox, g.inv_cell, g.nx);
+        const int cy = lio_cell_coord(qy, g.oy, g.inv_cell, g.ny);
+        const int cz = lio_cell_coord(qz, g.oz, g.inv_cell, g.nz);
+        bool act = inr;
+        act = act && (fabsf(qx) <= 3.0e38f) && (fabsf(qy) <= 3.0e38f) && (fabsf(qz) <= 3.0e38f);
+        act = act && cx >= -g.k && cx < g.nx + g.k && cy >= -g.k && cy < g.ny + g.k && cz >= -g.k && cz < g.nz + g.k;
+
+        // ---- exact 5-NN (MO:1631) inside the search bound of the previous iteration (see k_s2m_iterate)
+        float bound2 = P.c.max_sq_dist;
+        int xlo = -0x7fffffff, xhi = 0x7fffffff;
+        if (use_cache && act) {
+            const float d5 = P.d5_cache[ci];
+            if (d5 >= 0.0f) {
+                const float ox = Tp[0] * px + Tp[1] * py + Tp[2]  * pz + Tp[3];
+                const float oy = Tp[4] * px + Tp[5] * py + Tp[6]  * pz + Tp[7];
+                const float oz = Tp[8] * px + Tp[9] * py + Tp[10] * pz + Tp[11];
+                const float mv = sqrtf(lio_sqdist(qx, qy, qz, ox, oy, oz));
+                const float R = (sqrtf(d5) + mv) * 1.0001f + 1e-6f;
+                const float r2 = R * R * 1.0001f;
+                if (r2 < bound2) {
+                    bound2 = r2;
+                    xlo = lio_cell_coord(qx - R, g.ox, g.inv_cell, g.nx);
+                    xhi = lio_cell_coord(qx + R, g.ox, g.inv_cell, g.nx);
+                }
+            }
+        }
+        const double sentinel = lio_make_key(bound2, -1);
+        LioTop5 top = { sentinel, sentinel, sentinel, sentinel, sentinel };
+        if (act) lio_knn_global(P, g, qx, qy, qz, cx, cy, cz, xlo, xhi, top);
+        const bool ok = act && (lio_key_d2(top.k4) < P.c.max_sq_dist);       // gate MO:1641
+        const int nn[5] = { lio_key_idx(top.k0), lio_key_idx(top.k1), lio_key_idx(top.k2), lio_key_idx(top.k3), lio_key_idx(top.k4) };
+        if (P.d5_cache && inr) P.d5_cache[ci] = ok ? lio_key_d2(top.k4) : -1.0f;
+
+        // ---- plane, weight, coefficients MO:1642-1683
+        float cxx = 0.0f, cyy = 0.0f, czz = 0.0f, cww = 0.0f;
+        bool accept = false;
+        if (ok) accept = lio_assoc_point<false>(P, nn, qx, qy, qz, px, py, pz, cxx, cyy, czz, cww);
+        if (record && inr) {
+            const int oi = P.perm ? P.perm[base + li] : base + li;          // the record is kept in the CALLER's point order
+            P.rec_flag[oi] = accept ? 1 : 0;
+            reinterpret_cast<float4*>(P.rec_coeff)[oi] = make_float4(cxx, cyy, czz, cww);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) P.rec_nn[(size_t)oi * 5 + j] = ok ? nn[j] : -1;
+        }
+        // ---- row of matA / matB MO:1735-1778, sums MO:1781-1783 in k_s2m_iterate's order
+        float row[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, rhs = 0.0f;
+        if (accept) lio_jacobian_row(tr, px, py, pz, cxx, cyy, czz, cww, P.c.jac_exact, row, rhs);
+        {
+            double2* dst = reinterpret_cast<double2*>(s_rows[threadIdx.x]);
+            dst[0] = make_double2((double)row[0], (double)row[1]);
+            dst[1] = make_double2((double)row[2], (double)row[3]);
+            dst[2] = make_double2((double)row[4], (double)row[5]);
+            dst[3] = make_double2((double)rhs, accept ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        double red_acc = 0.0;
+        if (red_s < 28) {
+#pragma unroll 8
+            for (int p = red_g; p < LIO_BLOCK; p += 8)
+                red_acc = __builtin_fma(s_rows[p][red_a], s_rows[p][red_b], red_acc);
+            s_part[red_g][red_s] = red_acc;
+        }
+        __syncthreads();
+
+        if (wave == 0) {
+            double* part = P.partials + ((size_t)bd.scan * P.max_blk + bd.blk) * LIO_SUMS;
+            if (lane < 28) {
+                double v = s_part[0][lane];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) v += s_part[w][lane];
+                __hip_atomic_store(part + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int last = 0;
+            if (lane == 0) {
+                const unsigned old = atomicAdd(&P.arrive[bd.scan], 1u);
+                last = (old == (unsigned)bd.n_blk - 1u);
+            }
+            last = __shfl(last, 0);
+            if (last) {
+                // last workgroup of the scan in this iteration: fixed-order sum over the chunks, then LMOptimization
+                if (lane < 28) {
+                    const double* base_p = P.partials + (size_t)bd.scan * P.max_blk * LIO_SUMS + lane;
+                    double v = 0.0;
+                    for (int b = 0; b < bd.n_blk; b += 8) {
+                        double t[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            t[u] = __hip_atomic_load(base_p + (size_t)min(b + u, bd.n_blk - 1) * LIO_SUMS,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v += (b + u < bd.n_blk) ? t[u] : 0.0;
+                    }
+                    s_sum[lane] = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&P.arrive[bd.scan], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+                lio_gn_step(st, s_sum, P.c, &s_ws, P.n_active, lane);
+                // publish: the state written above becomes visible to the other XCDs before the generation number does
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) __hip_atomic_store(&gen[bd.scan], (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // per-scan barrier: wait for this iteration's solve (bounded)
+            int ctl = 0;
+            if (lane == 0) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(&gen[bd.scan], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(it + 1)) {
+                    if (++spins > LIO_PERSIST_SPIN_MAX) { ctl = 2; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                if (ctl == 2) atomicExch(fault, 1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // pairs with the solver's release
+                s_ctl = ctl;
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // the solver's writes to *st, not stale cache lines
+        if (s_ctl == 2) return;
+        if (__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // MO:1857-1858 / MO:1848, workgroup-uniform
+        if (it + 1 >= 32) return;                                          // (LIO_MAX_ITERS; max_iters <= 32 sets done before this)
+        __syncthreads();                                                   // s_ctl / s_part are rewritten by the next trip
+    }
+}
+
+}  // namespace
+
+void lio_launch_persist(const LioIterParams& P, int n_blocks, unsigned* gen, int n_scans, int* fault, hipStream_t s)
+{
+    if (n_blocks <= 0) return;
+    (void)hipMemsetAsync(gen, 0, sizeof(unsigned) * (size_t)n_scans, s);
+    (void)hipMemsetAsync(fault, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_s2m_persist, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, P, gen, fault);
+}

@@ -115,6 +115,10 @@ struct lio_s2m_handle {
     // split pipeline (cfg.pipeline): neighbour cache + per-iteration scan work list
     bool split = false;               // the resident batch runs k_s2m_cert / _scan / _fit instead of k_s2m_iterate
     bool certk = false;               // the resident batch runs k_s2m_iterate_cert (cfg.pipeline = 3)
+    // one-launch loop (cfg.pipeline = 4, k_s2m_persist): per-scan generation numbers + one fault word behind them
+    unsigned* d_gen = nullptr; size_t cap_gen = 0;
+    int n_cu = 0;                     // compute units of the device: every workgroup of a one-launch loop must be resident
+    bool run_persist = false;
     bool cache_dirty = true;          // map or batch changed: the neighbour cache must be dropped before the next run
     std::vector<LioGroupDesc> v_groups;
     LioGroupDesc* d_groups = nullptr; size_t cap_groups = 0;
@@ -276,12 +280,15 @@ static int lio_s2m_init_resources(lio_s2m_handle* h)
         HIPCHK(hipEventCreate(&h->ev_end[i]));
         HIPCHK(hipEventCreateWithFlags(&h->ev_chk[i], hipEventDisableTiming));
     }
-    HIPCHK(hipHostMalloc((void**)&h->h_active, sizeof(int) * LIO_MAX_ITERS, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&h->h_active, sizeof(int) * (LIO_MAX_ITERS + 1), hipHostMallocDefault));   // (+1: fault word of the one-launch loop)
     HIPCHK(hipEventCreate(&h->ev_map[0]));
     HIPCHK(hipEventCreate(&h->ev_map[1]));
     h->ev_ok = true;
     HIPCHK(hipMalloc((void**)&h->d_bbox, 6 * sizeof(unsigned)));
     HIPCHK(hipMalloc((void**)&h->d_active, sizeof(int)));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->cfg.device_id) == hipSuccess) h->n_cu = prop.multiProcessorCount;
+    (void)hipGetLastError();
     return LIO_OK;
 }
 
@@ -364,7 +371,7 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
                      h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
                      h->d_nn_cache, h->d_summary, h->d_groups, h->d_cache_idx, h->d_cache_q, h->d_pt_flag,
-                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox, h->d_block_box, h->d_blk_skip, h->d_plane, h->d_plane_state };
+                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox, h->d_block_box, h->d_blk_skip, h->d_plane, h->d_plane_state, h->d_gen };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < LIO_MAX_ITERS; ++i) {               // (a handle whose creation failed half-way holds nulls)
         if (h->ev_beg[i]) (void)hipEventDestroy(h->ev_beg[i]);
@@ -1321,7 +1328,10 @@ static int lio_run_continue(lio_s2m_handle* h, bool blocking)
             if (h->h_active[chk] == 0) break;
         }
         if (prof) HIPCHK(hipEventRecord(h->ev_beg[u], h->stream));
-        if (h->run_graph) HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
+        if (h->run_persist) {
+            lio_launch_persist(h->run_P, h->n_blocks, h->d_gen, h->n_scans, (int*)(h->d_gen + h->n_scans), h->stream);
+            HIPCHK(hipMemcpyAsync(&h->h_active[LIO_MAX_ITERS], h->d_gen + h->n_scans, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        } else if (h->run_graph) HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
         else lio_launch_gn(h, h->run_P, Pc);
         if (prof) HIPCHK(hipEventRecord(h->ev_end[u], h->stream));
         HIPCHK(hipMemcpyAsync(&h->h_active[u], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1388,7 +1398,13 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
     int look = h->cfg.lookahead;
     if (look < 0) look = (h->total_pts >= 200000) ? 0 : 2;
     // use_graph: a unit is one replay of a captured chunk of `graph_iters` iterations
-    const bool graph = h->cfg.use_graph != 0 && h->cfg.profile != 2 && h->cfg.record_corr_iter < 0 && h->n_blocks > 0;
+    // cfg.pipeline = 4: the whole loop as one launch (k_s2m_persist, lio_persist.hip) when every workgroup of the batch
+    // can be resident at once -- at most one per compute unit, a rule that holds whatever else runs on the device --
+    // and the batch uses nothing but the default surf association.  Otherwise the launch loop runs as usual.
+    h->run_persist = h->cfg.pipeline == 4 && !h->run_has_c && !h->split && !h->certk && !h->cfg.use_lds && h->ppt == 1 &&
+                     h->shard.axis < 0 && h->block_world == 1 && h->cfg.profile != 2 && h->n_blocks > 0 && h->n_cu > 0 &&
+                     h->n_blocks <= h->n_cu;
+    const bool graph = !h->run_persist && h->cfg.use_graph != 0 && h->cfg.profile != 2 && h->cfg.record_corr_iter < 0 && h->n_blocks > 0;
     int chunk = 1;
     if (graph) {
         chunk = h->cfg.graph_iters > 0 ? h->cfg.graph_iters : 4;
@@ -1396,11 +1412,16 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
         if ((rc = lio_graph_prepare(h, P, h->run_has_c ? &h->run_Pc : nullptr, chunk)) != LIO_OK) return rc;
         if (h->cfg.lookahead < 0) look = 0;              // a chunk already is a run-ahead of `chunk` launches
     }
+    if (h->run_persist) {
+        HIPCHK(lio_grow(&h->d_gen, &h->cap_gen, (size_t)h->n_scans + 1));
+        chunk = h->cfg.max_iters;                        // one unit = the whole loop
+        h->h_active[LIO_MAX_ITERS] = 0;
+    }
     h->run_graph = graph;
     h->run_look = look;
     h->run_units = (h->cfg.max_iters + chunk - 1) / chunk;
     h->run_next = 0;
-    h->unit_iters = chunk;
+    h->unit_iters = h->run_persist ? 1 : chunk;
     h->units_this_run = 0;
     h->launches_this_run = 0;
     h->run_pending = true;
@@ -1547,6 +1568,8 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
         }
     }
     HIPCHK(hipGetLastError());
+    if (h->run_persist && h->h_active[LIO_MAX_ITERS] != 0)
+        return lio_fail(LIO_ERR_HIP, "the one-launch loop gave up waiting for a solve (cfg.pipeline = 4); results are incomplete");
     int64_t pit = 0;
     for (int s = 0; s < h->n_scans; ++s) {
         const LioScanState& st = h->h_state[s];
@@ -1590,7 +1613,7 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
     }
     h->prof.n_units = n_units;
     h->prof.unit_iters = h->unit_iters;
-    h->prof.pipeline = h->split ? 2 : (h->certk ? 3 : 1);
+    h->prof.pipeline = h->split ? 2 : (h->certk ? 3 : (h->run_persist ? 4 : 1));
     memset(h->prof.cert_points, 0, sizeof(h->prof.cert_points));
     memset(h->prof.scan_points, 0, sizeof(h->prof.scan_points));
     if (h->split && h->cfg.profile && h->d_split_stats && !h->v_groups.empty()) {

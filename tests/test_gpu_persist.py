@@ -1,0 +1,104 @@
+"""The one-launch Gauss-Newton loop (cfg.pipeline = 4, k_s2m_persist, lio-slam_amd/csrc/lio_persist.hip) against the
+launch loop of k_s2m_iterate and the CPU oracle: scan2MapOptimization's 30-iteration loop MO:1848-1859 runs inside one
+kernel, the workgroups of a scan meet at a per-scan barrier after every LMOptimization (MO:1702-1837).  Nothing
+observable may change: every iteration's pose, correspondence count, the last normal matrix, matP, the recorded
+association of any iteration, on single registrations, ragged batches, scans that are refused (too few points) or
+give up (fewer than 50 correspondences), a degenerate corridor, and the fallback to the launch loop when the batch
+does not fit one workgroup per compute unit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _register(pkg, case_map, scan, pose0, **cfg):
+    s2m = pkg.ScanToMap(profile=1, **cfg)
+    s2m.set_map(case_map)
+    pose, res, rc = s2m.scan2MapOptimization(scan, pose0)
+    corr = s2m.get_correspondences(0) if cfg.get("record_corr_iter", -1) >= 0 else None
+    prof = s2m.profile()
+    s2m.close()
+    return pose, res, rc, corr, prof
+
+
+def _same_result(ra, rb):
+    assert ra.status == rb.status and ra.iters == rb.iters and ra.converged == rb.converged and ra.is_degenerate == rb.is_degenerate
+    assert ra.n_corr_last == rb.n_corr_last and list(ra.n_corr_iter) == list(rb.n_corr_iter)
+    np.testing.assert_array_equal(np.array(ra.pose_iter, np.float32).view(np.uint32), np.array(rb.pose_iter, np.float32).view(np.uint32))
+    for f in ("AtA", "AtB", "matP"):
+        np.testing.assert_array_equal(np.array(getattr(ra, f), np.float32).view(np.uint32),
+                                      np.array(getattr(rb, f), np.float32).view(np.uint32))
+
+
+@pytest.mark.parametrize("rec", [-1, 0, 3])
+@pytest.mark.parametrize("force", [0, 1])
+def test_one_launch_loop_equals_launch_loop(pkg, oracle, small_case, rec, force):
+    for q in small_case["queries"]:
+        kw = dict(record_corr_iter=rec, force_all_iters=force, max_iters=30 if not force else 8)
+        loop = _register(pkg, small_case["map"], q["scan"], q["pose_init"], pipeline=1, **kw)
+        one = _register(pkg, small_case["map"], q["scan"], q["pose_init"], pipeline=4, **kw)
+        assert loop[4].pipeline == 1 and one[4].pipeline == 4
+        assert one[4].n_launches == 1 and loop[4].n_launches >= loop[1].iters
+        assert loop[2] == one[2]
+        np.testing.assert_array_equal(loop[0], one[0])
+        _same_result(loop[1], one[1])
+        if rec >= 0:
+            for x, y in zip(loop[3], one[3]):
+                np.testing.assert_array_equal(np.ascontiguousarray(x).view(np.uint8), np.ascontiguousarray(y).view(np.uint8))
+            ocfg = oracle.default_config(knn_mode=1, n_threads=8, force_all_iters=force, max_iters=kw["max_iters"])
+            _, ro, _, corr = oracle.scan2map(ocfg, q["scan"], small_case["map"], q["pose_init"], corr_iter=rec)
+            np.testing.assert_array_equal(one[3][0], corr[0])
+            np.testing.assert_array_equal(one[3][2], corr[2])
+            assert list(ro.n_corr_iter)[:ro.iters] == list(one[1].n_corr_iter)[:ro.iters]
+
+
+def test_one_launch_loop_ragged_batch_with_refused_and_starved_scans(pkg, small_case):
+    qs = small_case["queries"]
+    far = qs[0]["scan"] + np.float32(500.0)                     # nowhere near the map: < 50 correspondences, MO:1721-1724
+    scans = [qs[0]["scan"], qs[1]["scan"][:700], qs[2]["scan"][:20], far[:900], qs[2]["scan"][::3], qs[1]["scan"][:257]]
+    poses0 = np.stack([qs[0]["pose_init"], qs[1]["pose_init"], qs[2]["pose_init"], qs[0]["pose_init"], qs[2]["pose_init"], qs[1]["pose_init"]])
+    outs = []
+    for pipe in (1, 4):
+        s = pkg.ScanToMap(pipeline=pipe, profile=1, sort_scan=2)
+        s.set_map(small_case["map"])
+        s.batch_upload(scans); s.batch_set_poses(poses0); s.batch_run()
+        p, r = s.batch_results()
+        assert s.profile().pipeline == pipe
+        # a second run on the same handle (arrival counters and generation numbers are re-armed)
+        s.batch_set_poses(poses0); s.batch_run()
+        p2, r2 = s.batch_results()
+        np.testing.assert_array_equal(p, p2)
+        outs.append((p, r))
+        s.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        _same_result(a, b)
+    assert [x.status for x in outs[1][1]] == [0, 0, 1, 2, 0, 0]
+
+
+def test_one_launch_loop_degenerate_corridor(pkg, synth):
+    case = synth.make_case("vlp16", n_keyframes=5, seed=3, kind="corridor", device="cpu")
+    q = case["queries"][0]
+    loop = _register(pkg, case["map"], q["scan"], q["pose_init"], pipeline=1)
+    one = _register(pkg, case["map"], q["scan"], q["pose_init"], pipeline=4)
+    assert one[1].is_degenerate == 1
+    np.testing.assert_array_equal(loop[0], one[0])
+    _same_result(loop[1], one[1])
+
+
+def test_batches_that_do_not_fit_fall_back_to_the_launch_loop(pkg, small_case):
+    """More workgroups than compute units: every workgroup of a one-launch loop must be resident, so the library runs
+    the launch loop instead and says so in the profile."""
+    qs = small_case["queries"]
+    scans = [qs[k % len(qs)]["scan"] for k in range(40)]        # 40 scans x ~8 workgroups > 256
+    poses0 = np.stack([qs[k % len(qs)]["pose_init"] for k in range(40)])
+    outs = []
+    for pipe in (1, 4):
+        s = pkg.ScanToMap(pipeline=pipe, profile=1)
+        s.set_map(small_case["map"])
+        s.batch_upload(scans); s.batch_set_poses(poses0); s.batch_run()
+        p, _ = s.batch_results()
+        assert s.profile().pipeline == 1
+        outs.append(p)
+        s.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
