@@ -60,12 +60,13 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
                           int* cell_of, int* cell_count, int* cell_start, int* tile_sums,
                           float4* sorted, int* nbr_start, float4* nbr_pts, hipStream_t s);
 int  lio_scan_tiles(int n_cells);
-void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c,
+void lio_launch_init_state(LioScanState* st, int n_scans, float* poses, bool from_state, const LioConsts& c,
                            int* n_active, hipStream_t s);
 void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s, bool corner = false);
 void lio_launch_split_iteration(const LioSplitParams& S, int n_blocks, hipStream_t s);
 void lio_launch_iterate_cert(const LioSplitParams& S, int n_blocks, hipStream_t s);
-void lio_launch_persist(const LioIterParams& P, int n_blocks, unsigned* gen, int n_scans, int* fault, hipStream_t s);
+void lio_launch_persist(const LioIterParams& P, int n_blocks, unsigned* gen, unsigned epoch, const unsigned char* stage, size_t stride,
+                        hipStream_t s);
 void lio_launch_pack_summary(const LioScanState* st, int n_scans, float* out, hipStream_t s);
 void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
                       int* n_active, hipStream_t s);

@@ -680,25 +680,37 @@ __global__ __launch_bounds__(256) void k_shard_cull(LioIterParams P, LioShardPla
 // Start of a registration: transformTobeMapped <- caller's guess, transform and
 // trig for the first pass, counters cleared.  matP / is_degenerate persist
 // (members MO:176-177).  Scans with N_s <= min_scan_pts are skipped (MO:1844).
+// from_state: the guess already sits in st[].pose (lio_s2m_register sends it with the state) and is copied to poses[],
+// where a second run on the same batch finds it.
+// SINGLE: the whole batch is one workgroup, which counts the scans itself -- no memset of *n_active before the launch.
+template <bool SINGLE>
 __global__ void k_s2m_init_state(LioScanState* __restrict__ st, int n_scans,
-                                 const float* __restrict__ poses, LioConsts c, int* __restrict__ n_active)
+                                 float* __restrict__ poses, int from_state, LioConsts c, int* __restrict__ n_active)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_scans) return;
-    LioScanState* p = &st[s];
-    float T[12], trig[6], pose[6];
-    for (int k = 0; k < 6; ++k) { pose[k] = poses[s * 6 + k]; p->pose[k] = pose[k]; }
-    lio_pose_to_transform(pose, T, trig);
-    for (int k = 0; k < 12; ++k) p->T[k] = T[k];
-    for (int k = 0; k < 6; ++k) p->trig[k] = trig[k];
-    p->iter = 0; p->converged = 0; p->n_corr_last = 0;
-    for (int k = 0; k < 32; ++k) { p->n_corr_iter[k] = 0; for (int j = 0; j < 6; ++j) p->pose_iter[k][j] = 0.0f; }
-    for (int k = 0; k < 36; ++k) p->AtA[k] = 0.0f;
-    for (int k = 0; k < 6; ++k) p->AtB[k] = 0.0f;
-    const bool enough = p->n_pts > c.min_scan_pts;
-    p->done = enough ? 0 : 1;
-    p->status = enough ? 0 : 1;
-    if (enough) atomicAdd(n_active, 1);
+    bool enough = false;
+    if (s < n_scans) {
+        LioScanState* p = &st[s];
+        float T[12], trig[6], pose[6];
+        if (from_state) { for (int k = 0; k < 6; ++k) { pose[k] = p->pose[k]; poses[s * 6 + k] = pose[k]; } }
+        else { for (int k = 0; k < 6; ++k) { pose[k] = poses[s * 6 + k]; p->pose[k] = pose[k]; } }
+        lio_pose_to_transform(pose, T, trig);
+        for (int k = 0; k < 12; ++k) p->T[k] = T[k];
+        for (int k = 0; k < 6; ++k) p->trig[k] = trig[k];
+        p->iter = 0; p->converged = 0; p->n_corr_last = 0;
+        for (int k = 0; k < 32; ++k) { p->n_corr_iter[k] = 0; for (int j = 0; j < 6; ++j) p->pose_iter[k][j] = 0.0f; }
+        for (int k = 0; k < 36; ++k) p->AtA[k] = 0.0f;
+        for (int k = 0; k < 6; ++k) p->AtB[k] = 0.0f;
+        enough = p->n_pts > c.min_scan_pts;
+        p->done = enough ? 0 : 1;
+        p->status = enough ? 0 : 1;
+    }
+    if (SINGLE) {
+        const int n = __syncthreads_count(enough ? 1 : 0);
+        if (threadIdx.x == 0) *n_active = n;
+    } else if (enough) {
+        atomicAdd(n_active, 1);
+    }
 }
 
 // ---- candidate scan, LDS form ---------------------------------------------
@@ -1068,7 +1080,7 @@ __global__ void k_s2m_pack_summary(const LioScanState* __restrict__ st, int n_sc
     if (s >= n_scans) return;
     float* o = out + (size_t)s * 10;
     for (int k = 0; k < 6; ++k) o[k] = st[s].pose[k];
-    o[6] = __int_as_float(st[s].iter); o[7] = __int_as_float(st[s].status);
+    o[6] = __int_as_float(st[s].iter); o[7] = __int_as_float(st[s].status | (st[s].done ? 0 : 0x100));   // (bit 8: still iterating)
     o[8] = __int_as_float(st[s].converged); o[9] = __int_as_float(st[s].is_degenerate);
 }
 
@@ -1134,11 +1146,16 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
 
 int lio_scan_tiles(int n_cells) { return (n_cells + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE; }
 
-void lio_launch_init_state(LioScanState* st, int n_scans, const float* poses, const LioConsts& c,
+void lio_launch_init_state(LioScanState* st, int n_scans, float* poses, bool from_state, const LioConsts& c,
                            int* n_active, hipStream_t s)
 {
+    const int fs = from_state ? 1 : 0;
+    if (n_scans <= 256) {              // one workgroup counts the active scans itself: one stream operation instead of two
+        hipLaunchKernelGGL(k_s2m_init_state<true>, dim3(1), dim3(n_scans <= 64 ? 64 : 256), 0, s, st, n_scans, poses, fs, c, n_active);
+        return;
+    }
     (void)hipMemsetAsync(n_active, 0, sizeof(int), s);
-    hipLaunchKernelGGL(k_s2m_init_state, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, poses, c, n_active);
+    hipLaunchKernelGGL(k_s2m_init_state<false>, dim3((n_scans + 63) / 64), dim3(64), 0, s, st, n_scans, poses, fs, c, n_active);
 }
 
 void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s, bool corner)

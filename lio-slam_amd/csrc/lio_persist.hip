@@ -7,10 +7,15 @@
 // What replaces the kernel boundary between two iterations is a PER-SCAN barrier, not a grid-wide one: the workgroups
 // of scan s only wait for scan s's solve.  The solving wave re-arms the arrival counter, releases (agent scope: its
 // XCD's L2 is written back) and publishes gen[s] = iterations done; wave 0 of every other workgroup of the scan polls
-// gen[s] with write-through loads, then the whole workgroup acquires (L1 / non-local L2 lines invalidated) and re-reads
-// the scan's state.  Every poll loop is bounded: after LIO_PERSIST_SPIN_MAX polls the workgroup raises *fault and
-// leaves, so every wave reaches an exit whatever happens (the host then reports LIO_ERR_HIP).
+// gen[s] (epoch + iterations done, so that nothing needs clearing between runs) with write-through loads, then the whole workgroup acquires (L1 / non-local L2 lines invalidated) and re-reads
+// the scan's state.  Every poll loop is bounded: after LIO_PERSIST_SPIN_MAX polls the workgroup leaves with the
+// scan's `done` flag still clear, so every wave reaches an exit whatever happens (the host finds a scan that is not done
+// after the launch and reports LIO_ERR_HIP).
 #include <hip/hip_runtime.h>
+#ifndef LIO_PREFETCH
+#define LIO_PREFETCH 2       // a lone registration runs ONE wave per SIMD: nothing else hides the candidate loads, so two groups are
+                             // kept in flight (the batched kernel, five waves per SIMD, is faster with one; lio_s2m_device.h)
+#endif
 #include "lio_kernels.h"
 #include "lio_device_math.h"
 #include "lio_s2m_device.h"
@@ -19,7 +24,7 @@
 
 namespace {
 
-__global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, unsigned* __restrict__ gen, int* __restrict__ fault)
+__global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, unsigned* __restrict__ gen, unsigned epoch, const unsigned char* __restrict__ stage, unsigned stride)
 {
     __shared__ __attribute__((aligned(16))) double s_rows[LIO_BLOCK][8];
     __shared__ double s_part[8][28];
@@ -36,7 +41,15 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
     const int li = bd.first + (int)threadIdx.x;
     const bool inr = li < n_pts;
     const int gi = base + (inr ? li : 0);
-    const float px = P.sx[gi], py = P.sy[gi], pz = P.sz[gi];             // the scan point never changes: loaded once
+    // the scan point never changes: loaded once -- straight from the staged records when the batch was not tile-sorted
+    // (the AoS -> SoA launch is skipped for it, see lio_s2m_batch_upload)
+    float px, py, pz;
+    if (stage) {
+        const float* rec = reinterpret_cast<const float*>(stage + (size_t)gi * stride);
+        px = rec[0]; py = rec[1]; pz = rec[2];
+    } else {
+        px = P.sx[gi]; py = P.sy[gi]; pz = P.sz[gi];
+    }
     const int ci = base + bd.first + (int)threadIdx.x;                   // slot in the batch SoA
     const int red_g = threadIdx.x >> 5, red_s = threadIdx.x & 31;
     const int red_a = c_pair_a[red_s], red_b = c_pair_b[red_s];
@@ -160,17 +173,16 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
                 lio_gn_step(st, s_sum, P.c, &s_ws, P.n_active, lane);
                 // publish: the state written above becomes visible to the other XCDs before the generation number does
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (lane == 0) __hip_atomic_store(&gen[bd.scan], (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(&gen[bd.scan], epoch + (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // per-scan barrier: wait for this iteration's solve (bounded)
             int ctl = 0;
             if (lane == 0) {
                 unsigned spins = 0;
-                while (__hip_atomic_load(&gen[bd.scan], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(it + 1)) {
+                while ((int)(__hip_atomic_load(&gen[bd.scan], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (epoch + (unsigned)(it + 1))) < 0) {
                     if (++spins > LIO_PERSIST_SPIN_MAX) { ctl = 2; break; }
                     __builtin_amdgcn_s_sleep(4);
                 }
-                if (ctl == 2) atomicExch(fault, 1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // pairs with the solver's release
                 s_ctl = ctl;
             }
@@ -186,10 +198,11 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
 
 }  // namespace
 
-void lio_launch_persist(const LioIterParams& P, int n_blocks, unsigned* gen, int n_scans, int* fault, hipStream_t s)
+// `epoch`: a number that grows by at least 64 from one launch on these buffers to the next (the generation numbers of a run
+// are epoch + 1 .. epoch + 32, compared modulo 2^32), so nothing has to be cleared between runs.
+void lio_launch_persist(const LioIterParams& P, int n_blocks, unsigned* gen, unsigned epoch, const unsigned char* stage, size_t stride,
+                        hipStream_t s)
 {
     if (n_blocks <= 0) return;
-    (void)hipMemsetAsync(gen, 0, sizeof(unsigned) * (size_t)n_scans, s);
-    (void)hipMemsetAsync(fault, 0, sizeof(int), s);
-    hipLaunchKernelGGL(k_s2m_persist, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, P, gen, fault);
+    hipLaunchKernelGGL(k_s2m_persist, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, P, gen, epoch, stage, (unsigned)stride);
 }

@@ -81,6 +81,8 @@ struct lio_s2m_handle {
     bool defer_sync = false;                         // lio_s2m_register: one sync at the end of the call
     bool async_upload = false;                       // lio_s2m_batch_upload_async: wait for the H2D copy only
     float* d_poses = nullptr; size_t cap_poses = 0;
+    const float* reg_pose = nullptr;  // lio_s2m_register: the initial guess travels inside the state upload
+    bool pose_in_state = false;       // ... and is taken from there by the next k_s2m_init_state (which copies it to d_poses)
     float* d_summary = nullptr; size_t cap_summary = 0;   // [n_scans][10] compact results (lio_s2m_batch_results without `results`)
     float* h_summary = nullptr; size_t cap_h_summary = 0; // pinned
     bool host_state_stale = false;    // h_state misses device-side updates (matP ...) since a summary-only read
@@ -115,10 +117,12 @@ struct lio_s2m_handle {
     // split pipeline (cfg.pipeline): neighbour cache + per-iteration scan work list
     bool split = false;               // the resident batch runs k_s2m_cert / _scan / _fit instead of k_s2m_iterate
     bool certk = false;               // the resident batch runs k_s2m_iterate_cert (cfg.pipeline = 3)
-    // one-launch loop (cfg.pipeline = 4, k_s2m_persist): per-scan generation numbers + one fault word behind them
+    // one-launch loop (cfg.pipeline = 4, k_s2m_persist): per-scan generation numbers
     unsigned* d_gen = nullptr; size_t cap_gen = 0;
+    unsigned gen_epoch = 0;           // grows by 64 per run: generation numbers are never cleared
     int n_cu = 0;                     // compute units of the device: every workgroup of a one-launch loop must be resident
     bool run_persist = false;
+    bool soa_valid = true;            // d_sx/d_sy/d_sz hold the resident batch (false: a one-launch batch still only staged as records)
     bool cache_dirty = true;          // map or batch changed: the neighbour cache must be dropped before the next run
     std::vector<LioGroupDesc> v_groups;
     LioGroupDesc* d_groups = nullptr; size_t cap_groups = 0;
@@ -280,7 +284,7 @@ static int lio_s2m_init_resources(lio_s2m_handle* h)
         HIPCHK(hipEventCreate(&h->ev_end[i]));
         HIPCHK(hipEventCreateWithFlags(&h->ev_chk[i], hipEventDisableTiming));
     }
-    HIPCHK(hipHostMalloc((void**)&h->h_active, sizeof(int) * (LIO_MAX_ITERS + 1), hipHostMallocDefault));   // (+1: fault word of the one-launch loop)
+    HIPCHK(hipHostMalloc((void**)&h->h_active, sizeof(int) * LIO_MAX_ITERS, hipHostMallocDefault));
     HIPCHK(hipEventCreate(&h->ev_map[0]));
     HIPCHK(hipEventCreate(&h->ev_map[1]));
     h->ev_ok = true;
@@ -738,6 +742,25 @@ static int lio_build_groups(lio_s2m_handle* h, const std::vector<LioBlockDesc>& 
 }
 
 // ------------------------------------------------------------------- batch
+// cfg.pipeline = 4: the whole Gauss-Newton loop as one launch (k_s2m_persist, lio_persist.hip) when every workgroup of the
+// batch can be resident at once -- at most one per compute unit, a rule that holds whatever else runs on the device --
+// and the batch uses nothing but the default surf association.  Otherwise the launch loop runs as usual.
+static bool lio_persist_eligible(const lio_s2m_handle* h)
+{
+    return h->cfg.pipeline == 4 && !h->split && !h->certk && !h->cfg.use_lds && h->ppt == 1 && h->shard.axis < 0 &&
+           h->block_world == 1 && h->cfg.profile != 2 && h->n_blocks > 0 && h->n_cu > 0 && h->n_blocks <= h->n_cu;
+}
+
+// The SoA copy of the resident batch, for the paths that read it, if the upload skipped it.
+static int lio_ensure_soa(lio_s2m_handle* h)
+{
+    if (h->soa_valid || !h->total_pts) return LIO_OK;
+    lio_launch_aos_to_soa(h->last_stage + h->last_xyz_off, h->last_stride, (int)h->total_pts, h->d_sx, h->d_sy, h->d_sz, nullptr, h->stream);
+    h->soa_valid = true;
+    HIPCHK(hipGetLastError());
+    return LIO_OK;
+}
+
 extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const void* const* scans,
                                     const size_t* n_pts, size_t stride)
 {
@@ -784,7 +807,14 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     HIPCHK(lio_grow(&h->d_stage, &h->cap_stage, tt * stride));
     HIPCHK(lio_grow(&h->d_state, &h->cap_state, (size_t)n_scans));
     HIPCHK(lio_grow(&h->d_poses, &h->cap_poses, (size_t)n_scans * 6));
-    HIPCHK(lio_grow(&h->d_arrive, &h->cap_arrive, (size_t)n_scans));
+    {
+        // every launch leaves the counters at zero (the last workgroup of a scan re-arms it): clear at allocation only
+        const unsigned* before = h->d_arrive;
+        const size_t cap_before = h->cap_arrive;
+        HIPCHK(lio_grow(&h->d_arrive, &h->cap_arrive, (size_t)n_scans));
+        if (h->d_arrive != before || h->cap_arrive != cap_before)
+            HIPCHK(hipMemsetAsync(h->d_arrive, 0, h->cap_arrive * sizeof(unsigned), h->stream));
+    }
     if (h->cfg.nn_cache && !h->cfg.use_lds) HIPCHK(lio_grow(&h->d_nn_cache, &h->cap_nn_cache, tt));
 
     // launch geometry: one workgroup = LIO_BLOCK * ppt consecutive points of one scan
@@ -821,6 +851,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         if ((size_t)s >= old_scans) memset(&st, 0, sizeof(st));   // keep matP / is_degenerate of live slots
         st.n_pts = (int)n_pts[s];
         st.offset = (int)off;
+        if (h->reg_pose && n_scans == 1) memcpy(st.pose, h->reg_pose, sizeof(float) * 6);
         st.c_n_pts = 0;                // a corner batch has to be uploaded again after every surf batch
         st.c_offset = 0;
         st.done = 1;
@@ -986,8 +1017,12 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
             h->sorted = true;
         }
     }
-    if (total && !h->sorted)
-        lio_launch_aos_to_soa(stage, stride, (int)total, h->d_sx, h->d_sy, h->d_sz, nullptr, h->stream);
+    h->soa_valid = true;
+    if (total && !h->sorted) {
+        // a batch the one-launch loop will take (lio_persist_eligible) reads its points once, from the records: no AoS -> SoA launch
+        if (lio_persist_eligible(h)) h->soa_valid = false;
+        else lio_launch_aos_to_soa(stage, stride, (int)total, h->d_sx, h->d_sy, h->d_sz, nullptr, h->stream);
+    }
     h->has_block_box = false;
     if (h->shard.axis >= 0 && ppt == 1 && !blocks.empty()) {
         // map sharding: the box of every workgroup's points, for the cull at the head of k_s2m_iterate
@@ -996,10 +1031,10 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         lio_launch_block_boxes(h->d_blocks, (int)blocks.size(), h->d_state, h->d_sx, h->d_sy, h->d_sz, h->d_block_box, h->stream);
         h->has_block_box = true;
     }
-    HIPCHK(hipMemsetAsync(h->d_arrive, 0, (size_t)n_scans * sizeof(unsigned), h->stream));
     if (!h->defer_sync) HIPCHK(hipStreamSynchronize(h->stream));   // the caller's scans are borrowed only for this call
     HIPCHK(hipGetLastError());
     h->poses_set = false;
+    h->pose_in_state = h->reg_pose != nullptr && n_scans == 1;
     h->ran = false;
     h->graph_dirty = true;
     h->corner_active = false;
@@ -1100,6 +1135,7 @@ extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     h->run_pending = false;            // (a run whose results were never fetched is abandoned)
+    h->pose_in_state = false;
     HIPCHK(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_scans * 6 * sizeof(float), hipMemcpyHostToDevice, h->stream));
     if (h->cfg.sort_batch && h->n_scans > 8 && !h->v_blocks.empty()) {
         // Locality only: order the workgroup list by where the scans ARE (position along the map's
@@ -1255,7 +1291,8 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     }
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
-    lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->c, h->d_active, h->stream);
+    lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->pose_in_state, h->c, h->d_active, h->stream);
+    h->pose_in_state = false;          // (d_poses holds the guess from now on)
     if (h->split && h->cfg.profile && h->d_split_stats)
         HIPCHK(hipMemsetAsync(h->d_split_stats, 0, h->v_groups.size() * LIO_MAX_ITERS * sizeof(int), h->stream));
     if ((h->split || h->certk) && h->cache_dirty) {
@@ -1329,12 +1366,12 @@ static int lio_run_continue(lio_s2m_handle* h, bool blocking)
         }
         if (prof) HIPCHK(hipEventRecord(h->ev_beg[u], h->stream));
         if (h->run_persist) {
-            lio_launch_persist(h->run_P, h->n_blocks, h->d_gen, h->n_scans, (int*)(h->d_gen + h->n_scans), h->stream);
-            HIPCHK(hipMemcpyAsync(&h->h_active[LIO_MAX_ITERS], h->d_gen + h->n_scans, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            lio_launch_persist(h->run_P, h->n_blocks, h->d_gen, h->gen_epoch, h->soa_valid ? nullptr : h->last_stage + h->last_xyz_off,
+                               h->last_stride, h->stream);
         } else if (h->run_graph) HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
         else lio_launch_gn(h, h->run_P, Pc);
         if (prof) HIPCHK(hipEventRecord(h->ev_end[u], h->stream));
-        HIPCHK(hipMemcpyAsync(&h->h_active[u], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (!h->run_persist) HIPCHK(hipMemcpyAsync(&h->h_active[u], h->d_active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipEventRecord(h->ev_chk[u], h->stream));
         h->run_next = u + 1;
         h->units_this_run = u + 1;
@@ -1398,12 +1435,8 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
     int look = h->cfg.lookahead;
     if (look < 0) look = (h->total_pts >= 200000) ? 0 : 2;
     // use_graph: a unit is one replay of a captured chunk of `graph_iters` iterations
-    // cfg.pipeline = 4: the whole loop as one launch (k_s2m_persist, lio_persist.hip) when every workgroup of the batch
-    // can be resident at once -- at most one per compute unit, a rule that holds whatever else runs on the device --
-    // and the batch uses nothing but the default surf association.  Otherwise the launch loop runs as usual.
-    h->run_persist = h->cfg.pipeline == 4 && !h->run_has_c && !h->split && !h->certk && !h->cfg.use_lds && h->ppt == 1 &&
-                     h->shard.axis < 0 && h->block_world == 1 && h->cfg.profile != 2 && h->n_blocks > 0 && h->n_cu > 0 &&
-                     h->n_blocks <= h->n_cu;
+    h->run_persist = lio_persist_eligible(h) && !h->run_has_c;         // (see lio_persist_eligible)
+    if (!h->run_persist && (rc = lio_ensure_soa(h)) != LIO_OK) return rc;
     const bool graph = !h->run_persist && h->cfg.use_graph != 0 && h->cfg.profile != 2 && h->cfg.record_corr_iter < 0 && h->n_blocks > 0;
     int chunk = 1;
     if (graph) {
@@ -1413,9 +1446,13 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
         if (h->cfg.lookahead < 0) look = 0;              // a chunk already is a run-ahead of `chunk` launches
     }
     if (h->run_persist) {
-        HIPCHK(lio_grow(&h->d_gen, &h->cap_gen, (size_t)h->n_scans + 1));
+        if ((size_t)h->n_scans > h->cap_gen || !h->d_gen) {
+            HIPCHK(lio_grow(&h->d_gen, &h->cap_gen, (size_t)h->n_scans));
+            HIPCHK(hipMemsetAsync(h->d_gen, 0, h->cap_gen * sizeof(unsigned), h->stream));   // (fresh generation numbers)
+            h->gen_epoch = 0;
+        }
+        h->gen_epoch += 64;
         chunk = h->cfg.max_iters;                        // one unit = the whole loop
-        h->h_active[LIO_MAX_ITERS] = 0;
     }
     h->run_graph = graph;
     h->run_look = look;
@@ -1435,6 +1472,7 @@ extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
     if (!h->ran) return lio_fail(LIO_ERR_ARG, "batch_begin first");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();
+    { const int rcs = lio_ensure_soa(h); if (rcs != LIO_OK) return rcs; }
     LioIterParams P;
     lio_fill_params(h, P, d_sums);
     HIPCHK(hipMemsetAsync(d_sums, 0, (size_t)h->n_scans * LIO_SUMS * sizeof(double), h->stream));
@@ -1564,12 +1602,18 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
             const float* o = h->h_summary + (size_t)s * 10;
             memcpy(st.pose, o, sizeof(float) * 6);
             memcpy(&st.iter, o + 6, 4); memcpy(&st.status, o + 7, 4);
+            st.done = (st.status & 0x100) ? 0 : 1;
+            st.status &= 0xff;
             memcpy(&st.converged, o + 8, 4); memcpy(&st.is_degenerate, o + 9, 4);
         }
     }
     HIPCHK(hipGetLastError());
-    if (h->run_persist && h->h_active[LIO_MAX_ITERS] != 0)
-        return lio_fail(LIO_ERR_HIP, "the one-launch loop gave up waiting for a solve (cfg.pipeline = 4); results are incomplete");
+    if (h->run_persist) {
+        // every scan leaves a one-launch loop done; one that did not gave up waiting at its barrier (bounded polls)
+        for (int s = 0; s < h->n_scans; ++s)
+            if (!h->h_state[s].done)
+                return lio_fail(LIO_ERR_HIP, "the one-launch loop gave up waiting for a solve (cfg.pipeline = 4); results are incomplete");
+    }
     int64_t pit = 0;
     for (int s = 0; s < h->n_scans; ++s) {
         const LioScanState& st = h->h_state[s];
@@ -1645,8 +1689,13 @@ extern "C" int lio_s2m_register(lio_s2m_handle* h, const void* scan, size_t n, s
     // upload, poses and the GN loop are chained on the stream; the only host wait is for the results
     // (the caller's buffers stay valid for the whole call)
     h->defer_sync = true;
+    if (!h->multi) h->reg_pose = pose;                   // one host-to-device copy less: the guess rides with the state
     int rc = lio_s2m_batch_upload(h, 1, scans, np, stride);
-    if (rc == LIO_OK) rc = lio_s2m_batch_set_poses(h, pose);
+    h->reg_pose = nullptr;
+    if (rc == LIO_OK) {
+        if (h->pose_in_state) h->poses_set = true;
+        else rc = lio_s2m_batch_set_poses(h, pose);
+    }
     if (rc == LIO_OK) rc = lio_s2m_batch_run(h);
     h->defer_sync = false;
     if (rc != LIO_OK) { (void)hipStreamSynchronize(h->stream); return rc; }

@@ -19,7 +19,8 @@ else:
 print(f"# lio_s2m_register, hdl64 scans N_s ~ {np.mean([len(q['scan']) for q in qs]):.0f} vs N_m = {len(map_xyz)}, incl. H2D of the scan and D2H of the result")
 for name, cfg in [("eager look=1", dict(lookahead=1)), ("eager look=2", dict(lookahead=2)), ("eager look=3", dict(lookahead=3)),
                   ("graph 3", dict(use_graph=1, graph_iters=3)), ("graph 4", dict(use_graph=1, graph_iters=4)),
-                  ("graph 6", dict(use_graph=1, graph_iters=6)), ("graph 8", dict(use_graph=1, graph_iters=8))]:
+                  ("graph 6", dict(use_graph=1, graph_iters=6)), ("graph 8", dict(use_graph=1, graph_iters=8)),
+                  ("one launch", dict(pipeline=4))]:
     s2m = pkg.ScanToMap(**cfg)
     s2m.set_map(map_xyz)
     for q in qs[:4]:
