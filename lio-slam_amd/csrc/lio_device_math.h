@@ -360,6 +360,65 @@ __device__ static int lio_solve6_qr(float* A, float* b, float* vl, float* hf)
     return 1;
 }
 
+// The same solve on PRIVATE arrays with every loop unrolled, so that the 6x6 system lives in registers: identical
+// operations in identical order (the solve sits at the end of every Gauss-Newton launch, on the critical path of a lone
+// registration; walking it through LDS cost ~10 us per iteration).
+__device__ static __forceinline__ int lio_solve6_qr_reg(float (&A)[36], float (&b)[6])
+{
+    const float eps = FLT_EPSILON * 10;
+    float vl[6], hf[6];
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        const int vs = 6 - l;
+        float vnorm = 0.0f;
+#pragma unroll
+        for (int i = 0; i < vs; ++i) { vl[i] = A[(l + i) * 6 + l]; vnorm += vl[i] * vl[i]; }
+        const float tmpv = vl[0];
+        const float sg = vl[0] >= 0.0f ? 1.0f : -1.0f;
+        vl[0] = vl[0] + sg * sqrtf(vnorm);
+        vnorm = sqrtf(vnorm + vl[0] * vl[0] - tmpv * tmpv);
+#pragma unroll
+        for (int i = 0; i < vs; ++i) vl[i] /= vnorm;
+#pragma unroll
+        for (int j = l; j < 6; ++j) {
+            float va = 0.0f;
+#pragma unroll
+            for (int i = l; i < 6; ++i) va += vl[i - l] * A[i * 6 + j];
+#pragma unroll
+            for (int i = l; i < 6; ++i) A[i * 6 + j] -= 2 * vl[i - l] * va;
+        }
+        hf[l] = vl[0] * vl[0];
+#pragma unroll
+        for (int i = 1; i < vs; ++i) A[(l + i) * 6 + l] = vl[i] / vl[0];
+    }
+#pragma unroll
+    for (int l = 0; l < 6; ++l) {
+        vl[0] = 1.0f;
+#pragma unroll
+        for (int j = 1; j < 6 - l; ++j) vl[j] = A[(j + l) * 6 + l];
+        float vb = 0.0f;
+#pragma unroll
+        for (int i = l; i < 6; ++i) vb += vl[i - l] * b[i];
+#pragma unroll
+        for (int i = l; i < 6; ++i) b[i] -= 2 * vl[i - l] * vb * hf[l];
+    }
+    bool singular = false;
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        if (!singular) {
+#pragma unroll
+            for (int j = 5; j > i; --j) b[i] -= b[j] * A[i * 6 + j];
+            if (fabsf(A[i * 6 + i]) < eps) singular = true;
+            else b[i] /= A[i * 6 + i];
+        }
+    }
+    if (singular) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) b[p] = 0.0f;
+        return 0;
+    }
+    return 1;
+}
 
 // cv::eigen(matAtA, matE, matV), MO:1792 (OpenCV JacobiImpl_: largest
 // off-diagonal pivot tracked per row/column; eigenvalues sorted descending,
@@ -612,5 +671,23 @@ __device__ static void lio_pose_to_transform(const float pose[6], float T[12], f
     T[4] = B * C;  T[5] = A * E + B * DF;  T[6]  = B * DE - A * F;  T[7]  = pose[4];
     T[8] = -D;     T[9] = C * F;           T[10] = C * E;           T[11] = pose[5];
     // LMOptimization's names (MO:1714-1719): srx=sin(yaw) ... crz=cos(roll)
+    trig[0] = B; trig[1] = A; trig[2] = D; trig[3] = C; trig[4] = F; trig[5] = E;
+}
+
+// The same for a pose held by lane 0 of a wave, ALL lanes calling: the six fp64 sines / cosines (a few hundred
+// instructions each) are evaluated by six lanes side by side -- the same function of the same argument, so the same bits --
+// and lane 0 assembles T and trig (only lane 0's T / trig are written).
+__device__ static void lio_pose_to_transform_wave(const float pose[6], float* T, float* trig, int lane)
+{
+    const float roll = __shfl(pose[0], 0), pitch = __shfl(pose[1], 0), yaw = __shfl(pose[2], 0);
+    const int f = lane % 6;
+    const float ang = f < 2 ? yaw : (f < 4 ? pitch : roll);
+    const float v = (f & 1) ? lio_sinf(ang) : lio_cosf(ang);          // lane f: 0 cos yaw, 1 sin yaw, 2 cos pitch, 3 sin pitch, 4 cos roll, 5 sin roll
+    const float A = __shfl(v, 0), B = __shfl(v, 1), C = __shfl(v, 2), D = __shfl(v, 3), E = __shfl(v, 4), F = __shfl(v, 5);
+    if (lane != 0) return;
+    const float DE = D * E, DF = D * F;
+    T[0] = A * C;  T[1] = A * DF - B * E;  T[2]  = B * F + A * DE;  T[3]  = pose[3];
+    T[4] = B * C;  T[5] = A * E + B * DF;  T[6]  = B * DE - A * F;  T[7]  = pose[4];
+    T[8] = -D;     T[9] = C * F;           T[10] = C * E;           T[11] = pose[5];
     trig[0] = B; trig[1] = A; trig[2] = D; trig[3] = C; trig[4] = F; trig[5] = E;
 }

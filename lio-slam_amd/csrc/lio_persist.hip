@@ -54,6 +54,12 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
     const int red_g = threadIdx.x >> 5, red_s = threadIdx.x & 31;
     const int red_a = c_pair_a[red_s], red_b = c_pair_b[red_s];
     if (st->done) return;                                                // (too few points: k_s2m_init_state) workgroup-uniform
+    // diagnostic phase clock (cfg.profile = 2): time of wave 0 of every workgroup, summed over the iterations, in 10 ns ticks:
+    // [0] state + transform, [1] candidate scan, [2] plane + row, [3] sums, [4] partial + arrival, [5] solve (solving
+    // workgroup only), [6] waiting at the scan's barrier, [7] acquire
+    long long* stamp = (P.stamps && wave == 0 && lane == 0) ? P.stamps + (size_t)wg * (LIO_BLOCK / 64) * 8 : nullptr;
+    long long t_prev = stamp ? (long long)wall_clock64() : 0;
+#define LIO_TICK(k) do { if (stamp) { const long long t_ = (long long)wall_clock64(); stamp[k] += t_ - t_prev; t_prev = t_; } } while (0)
 
 #pragma unroll 1
     for (int it = 0;; ++it) {
@@ -80,6 +86,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
         act = act && (fabsf(qx) <= 3.0e38f) && (fabsf(qy) <= 3.0e38f) && (fabsf(qz) <= 3.0e38f);
         act = act && cx >= -g.k && cx < g.nx + g.k && cy >= -g.k && cy < g.ny + g.k && cz >= -g.k && cz < g.nz + g.k;
 
+        LIO_TICK(0);
         // ---- exact 5-NN (MO:1631) inside the search bound of the previous iteration (see k_s2m_iterate)
         float bound2 = P.c.max_sq_dist;
         int xlo = -0x7fffffff, xhi = 0x7fffffff;
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
         const bool ok = act && (lio_key_d2(top.k4) < P.c.max_sq_dist);       // gate MO:1641
         const int nn[5] = { lio_key_idx(top.k0), lio_key_idx(top.k1), lio_key_idx(top.k2), lio_key_idx(top.k3), lio_key_idx(top.k4) };
         if (P.d5_cache && inr) P.d5_cache[ci] = ok ? lio_key_d2(top.k4) : -1.0f;
+        LIO_TICK(1);
 
         // ---- plane, weight, coefficients MO:1642-1683
         float cxx = 0.0f, cyy = 0.0f, czz = 0.0f, cww = 0.0f;
@@ -128,6 +136,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
             dst[3] = make_double2((double)rhs, accept ? 1.0 : 0.0);
         }
         __syncthreads();
+        LIO_TICK(2);
         double red_acc = 0.0;
         if (red_s < 28) {
 #pragma unroll 8
@@ -136,6 +145,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
             s_part[red_g][red_s] = red_acc;
         }
         __syncthreads();
+        LIO_TICK(3);
 
         if (wave == 0) {
             double* part = P.partials + ((size_t)bd.scan * P.max_blk + bd.blk) * LIO_SUMS;
@@ -152,6 +162,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
                 last = (old == (unsigned)bd.n_blk - 1u);
             }
             last = __shfl(last, 0);
+            LIO_TICK(4);
             if (last) {
                 // last workgroup of the scan in this iteration: fixed-order sum over the chunks, then LMOptimization
                 if (lane < 28) {
@@ -170,11 +181,18 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&P.arrive[bd.scan], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+                // (solver detail of the phase clock, slots 8-14: gather / step / release of iteration 0 and of the later ones, solves counted)
+                long long t_s = stamp ? (long long)wall_clock64() : 0;
+                const int so = it == 0 ? 8 : 11;
+                if (stamp) { stamp[so] += t_s - t_prev; if (it) stamp[14] += 1; }
                 lio_gn_step(st, s_sum, P.c, &s_ws, P.n_active, lane);
+                if (stamp) { const long long t_ = (long long)wall_clock64(); stamp[so + 1] += t_ - t_s; t_s = t_; }
                 // publish: the state written above becomes visible to the other XCDs before the generation number does
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (stamp) { const long long t_ = (long long)wall_clock64(); stamp[so + 2] += t_ - t_s; }
                 if (lane == 0) __hip_atomic_store(&gen[bd.scan], epoch + (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (last) LIO_TICK(5);
             // per-scan barrier: wait for this iteration's solve (bounded)
             int ctl = 0;
             if (lane == 0) {
@@ -188,12 +206,15 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
             }
         }
         __syncthreads();
+        LIO_TICK(6);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // the solver's writes to *st, not stale cache lines
         if (s_ctl == 2) return;
         if (__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // MO:1857-1858 / MO:1848, workgroup-uniform
         if (it + 1 >= 32) return;                                          // (LIO_MAX_ITERS; max_iters <= 32 sets done before this)
         __syncthreads();                                                   // s_ctl / s_part are rewritten by the next trip
+        LIO_TICK(7);
     }
+#undef LIO_TICK
 }
 
 }  // namespace

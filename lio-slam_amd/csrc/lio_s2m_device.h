@@ -111,18 +111,23 @@ LIO_DEV float lio_sqdist(float ax, float ay, float az, float bx, float by, float
 
 // The serial Gauss-Newton step of one scan: LMOptimization MO:1702-1837 from
 // the reduced sums onward, plus the loop control of scan2MapOptimization
-// MO:1848-1859.  One lane; `ws` is LDS (or any) working storage.
+// MO:1848-1859.  `ws` is LDS working storage.
+// Called by ALL lanes of one wave.  Lane 0 carries the serial algorithm, with the 6x6 system of cv::solve in its
+// registers (lio_solve6_qr_reg); the eigen-decomposition and the 6x6 product of the first iteration are spread over the
+// wave (lio_eigen6_sym_wave, lio_gemm6_wave), and so are the six fp64 sines / cosines of the next transform
+// (lio_pose_to_transform_wave).  This step ends every Gauss-Newton launch and is the critical path of a lone
+// registration ("one-launch loop").
 __device__ static void lio_gn_step(LioScanState* st, const double* sums, const LioConsts& c, LioSolveWs* ws,
                                    int* n_active, int lane)
 {
-    // Called by ALL lanes of one wave.  Lane 0 carries the serial algorithm; the eigen-decomposition and the
-    // 6x6 product of the first iteration are spread over the wave (lio_eigen6_sym_wave, lio_gemm6_wave).
     const int it = st->iter;
     const int nc = (int)sums[LIO_SUM_NC];
     const bool solve = nc >= c.min_corr;                       // MO:1721-1724 (wave-uniform)
-    float pose[6];
+    float pose[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    float X[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     bool conv = false;
     if (lane == 0) {
+#pragma unroll
         for (int k = 0; k < 6; ++k) pose[k] = st->pose[k];
         st->n_corr_last = nc;
         if (it < 32) st->n_corr_iter[it] = nc;
@@ -132,21 +137,26 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
         int deg = 0;
         if (lane == 0) {
             deg = st->is_degenerate;
+            float A[36];
             int p = 0;
+#pragma unroll
             for (int a = 0; a < 6; ++a)
+#pragma unroll
                 for (int b = a; b < 6; ++b) {
                     const float v = (float)sums[p++];
-                    ws->AtA[a * 6 + b] = v; ws->AtA[b * 6 + a] = v;
+                    A[a * 6 + b] = v; A[b * 6 + a] = v;
                 }
-            for (int a = 0; a < 6; ++a) ws->AtB[a] = (float)sums[21 + a];
-            for (int k = 0; k < 36; ++k) { st->AtA[k] = ws->AtA[k]; ws->A[k] = ws->AtA[k]; }
-            for (int k = 0; k < 6; ++k) { st->AtB[k] = ws->AtB[k]; ws->X[k] = ws->AtB[k]; }
-
-            lio_solve6_qr(ws->A, ws->X, ws->vl, ws->hf);       // MO:1784
+#pragma unroll
+            for (int a = 0; a < 6; ++a) X[a] = (float)sums[21 + a];
+#pragma unroll
+            for (int k = 0; k < 36; ++k) { st->AtA[k] = A[k]; if (it == 0) ws->AtA[k] = A[k]; }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) st->AtB[k] = X[k];
+            lio_solve6_qr_reg(A, X);                           // MO:1784
         }
-        LIO_LDS_FENCE();
         const float* matP = st->matP;
         if (it == 0) {                                         // MO:1786-1808
+            LIO_LDS_FENCE();
             if (lane < 36) ws->A[lane] = ws->AtA[lane];
             LIO_LDS_FENCE();
             lio_eigen6_sym_wave(ws->A, ws->W, ws->V, ws->indR, ws->indC, lane);   // cv::eigen, MO:1792
@@ -173,44 +183,58 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
         }
         if (lane == 0) {
             if (deg) {                                         // MO:1810-1815
-                for (int k = 0; k < 6; ++k) ws->X2[k] = ws->X[k];
+                for (int k = 0; k < 6; ++k) ws->X2[k] = X[k];
                 lio_gemm32f(matP, ws->X2, ws->X, 6, 6, 1);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) X[k] = ws->X[k];
             }
-            for (int k = 0; k < 6; ++k) pose[k] += ws->X[k];   // MO:1817-1822
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pose[k] += X[k];       // MO:1817-1822
 
             // MO:1824-1831: rad2deg in float, squares/sqrt in double, stored as float
-            const double r0 = (double)(ws->X[0] * 57.29578f), r1 = (double)(ws->X[1] * 57.29578f), r2 = (double)(ws->X[2] * 57.29578f);
+            const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
             const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);
-            const double t0 = (double)(ws->X[3] * 100), t1 = (double)(ws->X[4] * 100), t2 = (double)(ws->X[5] * 100);
+            const double t0 = (double)(X[3] * 100), t1 = (double)(X[4] * 100), t2 = (double)(X[5] * 100);
             const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);
             conv = ((double)deltaR < c.conv_deg) && ((double)deltaT < c.conv_cm);   // MO:1833
         }
     }
-    if (lane != 0) return;
 
-    for (int k = 0; k < 6; ++k) st->pose[k] = pose[k];
-    if (it < 32) for (int k = 0; k < 6; ++k) st->pose_iter[it][k] = pose[k];
-    int iters = it + 1;
     int done = 0;
-    if (conv) { st->converged = 1; if (!c.force_all) done = 1; }   // MO:1857-1858
-    if (iters >= c.max_iters) done = 1;                            // MO:1848
-    if (nc < c.min_corr && !done) {
-        // LMOptimization returned false WITHOUT touching the pose (MO:1721-1724):
-        // every remaining iteration would redo identical work.  Fast-forward.
-        for (int k = iters; k < c.max_iters && k < 32; ++k) {
-            st->n_corr_iter[k] = nc;
-            for (int j = 0; j < 6; ++j) st->pose_iter[k][j] = pose[j];
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) st->pose[k] = pose[k];
+        if (it < 32) for (int k = 0; k < 6; ++k) st->pose_iter[it][k] = pose[k];
+        int iters = it + 1;
+        if (conv) { st->converged = 1; if (!c.force_all) done = 1; }   // MO:1857-1858
+        if (iters >= c.max_iters) done = 1;                            // MO:1848
+        if (nc < c.min_corr && !done) {
+            // LMOptimization returned false WITHOUT touching the pose (MO:1721-1724):
+            // every remaining iteration would redo identical work.  Fast-forward.
+            for (int k = iters; k < c.max_iters && k < 32; ++k) {
+                st->n_corr_iter[k] = nc;
+                for (int j = 0; j < 6; ++j) st->pose_iter[k][j] = pose[j];
+            }
+            iters = c.max_iters;
+            done = 1;
         }
-        iters = c.max_iters;
-        done = 1;
+        st->iter = iters;
+        st->done = done;
+        st->status = (nc < c.min_corr) ? 2 : 0;
+        if (done && n_active) atomicSub(n_active, 1);
     }
-    st->iter = iters;
-    st->done = done;
-    st->status = (nc < c.min_corr) ? 2 : 0;
-    if (done && n_active) atomicSub(n_active, 1);
-    if (!done) {
-        for (int k = 0; k < 12; ++k) st->Tp[k] = st->T[k];         // (search bound of the next pass, see k_s2m_iterate)
-        lio_pose_to_transform(pose, st->T, st->trig);              // MO:1613-1616 for the next pass
+    done = __shfl(done, 0);
+    if (!done) {                                                   // wave-uniform
+        float Tn[12], trn[6];
+        lio_pose_to_transform_wave(pose, Tn, trn, lane);           // MO:1613-1616 for the next pass
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) st->Tp[k] = st->T[k];     // (search bound of the next pass, see k_s2m_iterate)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) st->T[k] = Tn[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) st->trig[k] = trn[k];
+        }
     }
 }
 

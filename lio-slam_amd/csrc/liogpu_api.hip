@@ -748,7 +748,7 @@ static int lio_build_groups(lio_s2m_handle* h, const std::vector<LioBlockDesc>& 
 static bool lio_persist_eligible(const lio_s2m_handle* h)
 {
     return h->cfg.pipeline == 4 && !h->split && !h->certk && !h->cfg.use_lds && h->ppt == 1 && h->shard.axis < 0 &&
-           h->block_world == 1 && h->cfg.profile != 2 && h->n_blocks > 0 && h->n_cu > 0 && h->n_blocks <= h->n_cu;
+           h->block_world == 1 && h->n_blocks > 0 && h->n_cu > 0 && h->n_blocks <= h->n_cu;
 }
 
 // The SoA copy of the resident batch, for the paths that read it, if the upload skipped it.
