@@ -601,6 +601,123 @@ __device__ static void lio_eigen6_sym_wave(float* A, float* W, float* V, int* in
     LIO_LDS_FENCE();
 }
 
+// The same decomposition with the matrices in REGISTERS, one element per lane (lane e < 36 holds A[e/6][e%6] and
+// V[e/6][e%6], lanes 0..5 also W[lane], indR[lane], indC[lane]): no LDS round trips and no fences inside the loop, which a
+// lone registration waits for ~34 times (the LDS form costs ~1.1 us per rotation).  Element reads with a wave-uniform
+// index are v_readlane, per-lane indices go through ds_bpermute; every floating-point operation and comparison is
+// the serial code's:
+//   pivot     lanes 0-4 fetch |A[i][indR[i]]|, lanes 1-5 |A[indC[i]][i]|; the serial scan (rows 0..4, then columns 1..5,
+//             strict `<`) picks the first row holding the row maximum unless the column maximum is strictly larger, then
+//             the first column holding it;
+//   rotation  the pairs the serial loops rotate are disjoint, so every lane that holds a member fetches its partner
+//             and applies its half of the rotation; the eigenvector rows k and l likewise;
+//   trackers  every lane 0..5 recomputes indR / indC of its own row / column from the rotated matrix, lanes k and l
+//             keep the result (the serial code recomputes exactly those).
+// All lanes of the wave must call it; Ain (36) is read from LDS, W (6) and V (36, eigenvectors as rows, eigenvalues
+// descending) are written to LDS.
+__device__ static void lio_eigen6_sym_lanes(const float* Ain, float* Wout, float* Vout, int lane)
+{
+#define LIO_BP(x, idx) __int_as_float(__builtin_amdgcn_ds_bpermute((idx) << 2, __float_as_int(x)))
+#define LIO_RL(x, idx) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (idx)))
+#define LIO_SHR(x, n) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x110 + (n), 0xf, 0xf, false))
+    // indR of row t (first maximum of |A[t][m]|, m > t) and indC of column t (first maximum of |A[i][t]|, i < t)
+#define LIO_TRACK(nr, nc) do {                                                                   \
+        float mv_ = -1.0f, mc_ = -1.0f; nr = 0; nc = 0;                                          \
+        _Pragma("unroll") for (int m_ = 1; m_ < 6; ++m_) {                                       \
+            const float val_ = fabsf(LIO_BP(a, t6 + m_));                                        \
+            if (m_ == t + 1 || (m_ > t && mv_ < val_)) { mv_ = val_; nr = m_; }                  \
+        }                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) {                                       \
+            const float val_ = fabsf(LIO_BP(a, i_ * 6 + t));                                     \
+            if (i_ < t && (i_ == 0 || mc_ < val_)) { mc_ = val_; nc = i_; }                      \
+        }                                                                                        \
+    } while (0)
+    const float eps = FLT_EPSILON;
+    const int r = lane / 6, c = lane - r * 6;
+    const bool in = lane < 36;
+    const int t = lane < 5 ? lane : 5, t6 = t * 6;
+    float a = in ? Ain[lane] : 0.0f;
+    float v = (in && r == c) ? 1.0f : 0.0f;
+    float w = LIO_BP(a, t * 7);                              // lanes 0..5: W[lane] = A[lane][lane]
+    int ir, ic;
+    LIO_TRACK(ir, ic);
+    for (int iters = 0; iters < 6 * 6 * 30; ++iters) {
+        // pivot
+        const float rvl = fabsf(LIO_BP(a, t6 + ir)), cvl = fabsf(LIO_BP(a, ic * 6 + t));
+        const bool is_row = lane < 5, is_col = lane >= 1 && lane <= 5;
+        const float rv = is_row ? rvl : -1.0f, cv = is_col ? cvl : -1.0f;
+        float x = rv, y_ = cv;
+        x = fmaxf(x, LIO_SHR(x, 1)); y_ = fmaxf(y_, LIO_SHR(y_, 1));
+        x = fmaxf(x, LIO_SHR(x, 2)); y_ = fmaxf(y_, LIO_SHR(y_, 2));
+        x = fmaxf(x, LIO_SHR(x, 4)); y_ = fmaxf(y_, LIO_SHR(y_, 4));
+        const float rmax = LIO_RL(x, 7), cmax = LIO_RL(y_, 7);       // maxima over lanes 0..7 (6, 7 hold -1)
+        const int kr = __builtin_ctzll(__ballot(is_row && rv == rmax) | (1ull << 63));
+        const int lc = __builtin_ctzll(__ballot(is_col && cv == cmax) | (1ull << 63));
+        const int l_row = __builtin_amdgcn_readlane(ir, kr & 7), k_col = __builtin_amdgcn_readlane(ic, lc & 7);
+        const bool colwins = cmax > rmax;
+        const int k = __builtin_amdgcn_readfirstlane(colwins ? k_col : kr);
+        const int l = __builtin_amdgcn_readfirstlane(colwins ? lc : l_row);
+        const float p = LIO_RL(a, k * 6 + l);
+        if (fabsf(p) <= eps) break;                          // wave-uniform
+        const float wk = LIO_RL(w, k), wl = LIO_RL(w, l);
+        const float y = (float)((wl - wk) * 0.5);
+        float tt = fabsf(y) + lio_cv_hypot(p, y);
+        float s = lio_cv_hypot(p, tt);
+        const float cc = tt / s;
+        s = p / s; tt = (p / tt) * p;
+        if (y < 0) { s = -s; tt = -tt; }
+        // rotation of the upper triangle: role 1 = first member of a pair (a0), role 2 = second member (b0)
+        int role = 0, pe = lane;
+        if (c == k && r < k) { role = 1; pe = r * 6 + l; }
+        else if (c == l && r < k) { role = 2; pe = r * 6 + k; }
+        else if (r == k && c > k && c < l) { role = 1; pe = c * 6 + l; }
+        else if (c == l && r > k && r < l) { role = 2; pe = k * 6 + r; }
+        else if (r == k && c > l) { role = 1; pe = l * 6 + c; }
+        else if (r == l && c > l) { role = 2; pe = k * 6 + c; }
+        const float pa = LIO_BP(a, pe);
+        const float n0 = a * cc - pa * s, n1 = pa * s + a * cc;
+        a = role == 1 ? n0 : (role == 2 ? n1 : a);
+        if (lane == k * 6 + l) a = 0;
+        // eigenvector rows k and l
+        const bool vk = in && r == k, vl = in && r == l;
+        const float pv = LIO_BP(v, vk ? l * 6 + c : (vl ? k * 6 + c : lane));
+        const float m0 = v * cc - pv * s, m1 = pv * s + v * cc;
+        v = vk ? m0 : (vl ? m1 : v);
+        if (lane == k) w = wk - tt;
+        if (lane == l) w = wl + tt;
+        int nr, nc;
+        LIO_TRACK(nr, nc);
+        if (lane == k || lane == l) { ir = nr; ic = nc; }
+    }
+    // descending selection sort of the eigenvalues, eigenvectors are rows (the permutation is wave-uniform)
+    float W[6];
+    int perm[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { W[i] = LIO_RL(w, i); perm[i] = i; }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        int m = k;
+        float wm = W[k];
+        int pm = perm[k];
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) if (wm < W[i]) { wm = W[i]; m = i; pm = perm[i]; }
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) if (m == i) { W[i] = W[k]; perm[i] = perm[k]; }
+        W[k] = wm; perm[k] = pm;
+    }
+    int pr = perm[0];
+    float ws_ = W[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) { if (r == i) pr = perm[i]; if (lane == i) ws_ = W[i]; }
+    const float vf = LIO_BP(v, in ? pr * 6 + c : lane);
+    if (in) Vout[lane] = vf;
+    if (lane < 6) Wout[lane] = ws_;
+#undef LIO_TRACK
+#undef LIO_SHR
+#undef LIO_RL
+#undef LIO_BP
+}
+
 // C(6x6) = A(6x6) * B(6x6), one lane per output element; the same double accumulation over k as lio_gemm32f.
 __device__ static void lio_gemm6_wave(const float* A, const float* B, float* C, int lane)
 {
@@ -641,6 +758,62 @@ __device__ static int lio_inv6_lu(float* A, float* B)
             B[i * 6 + j] = s / A[i * 6 + i];
         }
     return 1;
+}
+
+// The same inverse by a wave, ALL lanes calling: lane j (0..5) carries column j of [A | I] through the elimination with A
+// in registers (every lane eliminates its own copy of A: the pivot decisions are wave-uniform); the operations on
+// each element are the serial code's, in its order.  Vin (36, LDS) is only read; lanes 0..5 write B (LDS).
+__device__ static void lio_inv6_lu_wave(const float* Vin, float* B, int lane)
+{
+    const float eps = FLT_EPSILON * 10;
+    float A[36], Bc[6];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) A[k] = Vin[k];
+    const int col = lane % 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Bc[i] = (i == col) ? 1.0f : 0.0f;
+    bool singular = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        if (!singular) {                                     // wave-uniform
+            int k = i;
+            float best = fabsf(A[i * 6 + i]);
+#pragma unroll
+            for (int j = i + 1; j < 6; ++j) { const float v = fabsf(A[j * 6 + i]); if (v > best) { best = v; k = j; } }
+            if (best < eps) {
+                singular = true;
+            } else {
+#pragma unroll
+                for (int j = i + 1; j < 6; ++j)
+                    if (k == j) {                            // wave-uniform: rows i and j change places
+#pragma unroll
+                        for (int c = i; c < 6; ++c) { const float t = A[i * 6 + c]; A[i * 6 + c] = A[j * 6 + c]; A[j * 6 + c] = t; }
+                        const float t = Bc[i]; Bc[i] = Bc[j]; Bc[j] = t;
+                    }
+                const float d = -1 / A[i * 6 + i];
+#pragma unroll
+                for (int j = i + 1; j < 6; ++j) {
+                    const float alpha = A[j * 6 + i] * d;
+#pragma unroll
+                    for (int c = i + 1; c < 6; ++c) A[j * 6 + c] += alpha * A[i * 6 + c];
+                    Bc[j] += alpha * Bc[i];
+                }
+            }
+        }
+    }
+    if (!singular) {
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+            float s = Bc[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) s -= A[i * 6 + k] * Bc[k];
+            Bc[i] = s / A[i * 6 + i];
+        }
+    }
+    if (lane < 6) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) B[i * 6 + lane] = singular ? 0.0f : Bc[i];
+    }
 }
 
 // CV_32F matrix product (double accumulation over k, rounded once).

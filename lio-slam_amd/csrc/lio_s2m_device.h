@@ -157,9 +157,8 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
         const float* matP = st->matP;
         if (it == 0) {                                         // MO:1786-1808
             LIO_LDS_FENCE();
-            if (lane < 36) ws->A[lane] = ws->AtA[lane];
+            lio_eigen6_sym_lanes(ws->AtA, ws->W, ws->V, lane);  // cv::eigen, MO:1792
             LIO_LDS_FENCE();
-            lio_eigen6_sym_wave(ws->A, ws->W, ws->V, ws->indR, ws->indC, lane);   // cv::eigen, MO:1792
             if (lane == 0) {
                 for (int k = 0; k < 36; ++k) ws->V2[k] = ws->V[k];
                 deg = 0;
@@ -171,10 +170,10 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
                         break;
                     }
                 }
-                for (int k = 0; k < 36; ++k) ws->A[k] = ws->V[k];
-                lio_inv6_lu(ws->A, ws->B);
                 st->is_degenerate = deg;
             }
+            LIO_LDS_FENCE();
+            lio_inv6_lu_wave(ws->V, ws->B, lane);              // matV.inv(), MO:1807
             LIO_LDS_FENCE();
             lio_gemm6_wave(ws->B, ws->V2, ws->A, lane);        // matP = matV.inv() * matV2, MO:1807
             LIO_LDS_FENCE();

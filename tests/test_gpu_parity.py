@@ -45,6 +45,10 @@ def _assert_parity(g, o):
     assert np.array_equal(coeff[sel].view(np.uint32), coeff_o[sel].view(np.uint32)), "coefficients not bit-exact"
     assert np.abs(pose[3:] - pose_o[3:]).max() <= POSE_TOL_T
     assert np.abs(pose[:3] - pose_o[:3]).max() <= POSE_TOL_R
+    if res.iters > 0 and rc == 0:
+        # the eigen-decomposition / inverse / product chain of the first iteration (MO:1786-1808), bit for bit
+        assert np.array_equal(np.array(res.matP, np.float32).view(np.uint32), np.asarray(matP_o, np.float32).reshape(-1).view(np.uint32)), \
+            "matP differs from the oracle"
 
 
 def test_register_matches_oracle(pkg, oracle, small_case):
@@ -209,3 +213,33 @@ def test_hipgraph_loop_is_identical(pkg, small_case, graph_iters):
     p1, r1, _ = g.scan2MapOptimization(qs[2]["scan"], qs[2]["pose_init"])      # new geometry -> re-capture
     np.testing.assert_array_equal(p1, pe[2])
     eager.close(); g.close()
+
+
+def test_degeneracy_chain_is_bit_exact_on_many_normal_matrices(pkg, oracle, synth, small_case):
+    """cv::eigen (Jacobi), the degeneracy rule, matV.inv() and the product (MO:1786-1808) run once per registration, inside
+    the first Gauss-Newton launch, as register-resident wave code; isDegenerate and all 36 entries of matP must match the CPU
+    restatement bit for bit on well-conditioned scenes, on a degenerate corridor, and with perturbed and truncated inputs
+    (different normal matrices, different pivot sequences)."""
+    cases = [(small_case["map"], q["scan"], q["pose_init"]) for q in small_case["queries"]]
+    cor = synth.make_case("vlp16", n_keyframes=5, seed=3, kind="corridor", device="cpu")
+    cases += [(cor["map"], q["scan"], q["pose_init"]) for q in cor["queries"]]
+    rng = np.random.default_rng(17)
+    more = []
+    for m, sc, p0 in cases:
+        for k in range(4):
+            sub = sc[rng.permutation(len(sc))[: len(sc) // (k + 1)]]
+            pp = np.array(p0, np.float32) + rng.normal(0, [0.004, 0.004, 0.01, 0.05, 0.05, 0.02]).astype(np.float32)
+            more.append((m, np.ascontiguousarray(sub), pp))
+    n_deg = 0
+    for m, sc, p0 in cases + more:
+        s2m = pkg.ScanToMap(max_iters=2)
+        s2m.set_map(m)
+        _, res, rc = s2m.scan2MapOptimization(sc, p0)
+        s2m.close()
+        _, res_o, matP_o, _ = oracle.scan2map(oracle.default_config(knn_mode=1, n_threads=8, max_iters=2), sc, m, p0)
+        assert rc == res_o.status and res.is_degenerate == res_o.is_degenerate
+        n_deg += res.is_degenerate
+        if rc == 0:
+            assert np.array_equal(np.array(res.matP, np.float32).view(np.uint32), np.asarray(matP_o, np.float32).reshape(-1).view(np.uint32))
+            assert np.array_equal(np.array(res.AtA, np.float32).view(np.uint32), np.array(res_o.AtA, np.float32).view(np.uint32))
+    assert n_deg >= 2
