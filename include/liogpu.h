@@ -87,10 +87,15 @@ typedef struct lio_s2m_config {
     int32_t nn_cache;        /* 1 (default) = from the second GN iteration on, bound each point's
                                 search by the distances to its previous 5 neighbours (exact:
                                 the candidate run shrinks, the result does not change)      */
-    int32_t pipeline;        /* 0 / 1 = one fused launch per GN iteration (k_s2m_iterate); 2 = split: neighbour
-                                certificate / candidate scan / fit as three launches; 3 = the fused launch with
-                                the certificate inside (k_s2m_iterate_cert).  Identical results; 2 measured
-                                slower and 3 no faster on MI355X, both kept as options with their evidence   */
+    int32_t pipeline;        /* how the Gauss-Newton loop MO:1848-1859 is issued; results are identical for every value.
+                                0 = auto: one launch per iteration (k_s2m_iterate), or -- for a batch of at most a quarter
+                                of a workgroup per compute unit, e.g. a lone registration, unless use_graph or profile = 2
+                                is set -- the whole loop as ONE launch (k_s2m_persist: per-scan barrier between
+                                iterations; 0.21 against 0.25 ms per registration on MI355X); 1 = always one launch per
+                                iteration; 4 = the one-launch loop for every batch of at most one workgroup per compute
+                                unit; 2 = split: neighbour certificate / candidate scan / fit as three launches; 3 = the
+                                per-iteration launch with the certificate inside (k_s2m_iterate_cert); 2 measured slower
+                                and 3 no faster, both kept as options with their evidence                               */
     int32_t n_devices;       /* 1 (default) = the single device `device_id`.  > 1: in-library multi-GPU -- the local
                                 map is cut into slabs (+ one-cell halo) over device_ids[0..n_devices), every
                                 registration's points are processed by the device owning their map cell and the
@@ -126,7 +131,7 @@ typedef struct lio_s2m_profile {
     int64_t point_iters;       /* scan points processed by active scans over the run      */
     int64_t n_map;             /* resident map points                                     */
     int64_t n_cells;           /* grid cells                                              */
-    int32_t pipeline;          /* what the last run used: 1 = fused launches, 2 = split   */
+    int32_t pipeline;          /* what the last run used: 1 = one launch per iteration, 2 = split, 3 = certificate inside, 4 = one-launch loop */
     int32_t pad_;
     int64_t cert_points[LIO_MAX_ITERS]; /* split pipeline, per GN iteration: scan points looked at by the
                                   neighbour certificate ...                               */

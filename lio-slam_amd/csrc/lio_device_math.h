@@ -613,9 +613,9 @@ __device__ static void lio_eigen6_sym_wave(float* A, float* W, float* V, int* in
 //             and applies its half of the rotation; the eigenvector rows k and l likewise;
 //   trackers  every lane 0..5 recomputes indR / indC of its own row / column from the rotated matrix, lanes k and l
 //             keep the result (the serial code recomputes exactly those).
-// All lanes of the wave must call it; Ain (36) is read from LDS, W (6) and V (36, eigenvectors as rows, eigenvalues
-// descending) are written to LDS.
-__device__ static void lio_eigen6_sym_lanes(const float* Ain, float* Wout, float* Vout, int lane)
+// All lanes of the wave must call it; Ain (36) is read from LDS; the results stay in registers: Wd[0..5] = the eigenvalues
+// in descending order (wave-uniform), vrow = element (lane/6, lane%6) of the eigenvector matrix (eigenvectors as rows) in lanes 0..35.
+__device__ static void lio_eigen6_sym_lanes(const float* Ain, float (&Wd)[6], float& vrow, int lane)
 {
 #define LIO_BP(x, idx) __int_as_float(__builtin_amdgcn_ds_bpermute((idx) << 2, __float_as_int(x)))
 #define LIO_RL(x, idx) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (idx)))
@@ -706,12 +706,11 @@ __device__ static void lio_eigen6_sym_lanes(const float* Ain, float* Wout, float
         W[k] = wm; perm[k] = pm;
     }
     int pr = perm[0];
-    float ws_ = W[0];
 #pragma unroll
-    for (int i = 1; i < 6; ++i) { if (r == i) pr = perm[i]; if (lane == i) ws_ = W[i]; }
-    const float vf = LIO_BP(v, in ? pr * 6 + c : lane);
-    if (in) Vout[lane] = vf;
-    if (lane < 6) Wout[lane] = ws_;
+    for (int i = 1; i < 6; ++i) if (r == i) pr = perm[i];
+    vrow = LIO_BP(v, in ? pr * 6 + c : lane);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Wd[i] = W[i];
 #undef LIO_TRACK
 #undef LIO_SHR
 #undef LIO_RL
@@ -762,13 +761,14 @@ __device__ static int lio_inv6_lu(float* A, float* B)
 
 // The same inverse by a wave, ALL lanes calling: lane j (0..5) carries column j of [A | I] through the elimination with A
 // in registers (every lane eliminates its own copy of A: the pivot decisions are wave-uniform); the operations on
-// each element are the serial code's, in its order.  Vin (36, LDS) is only read; lanes 0..5 write B (LDS).
-__device__ static void lio_inv6_lu_wave(const float* Vin, float* B, int lane)
+// each element are the serial code's, in its order.  The matrix arrives one element per lane (vrow of lane e < 36 =
+// element (e/6, e%6)); lanes 0..5 write B (LDS).
+__device__ static void lio_inv6_lu_wave(float vrow, float* B, int lane)
 {
     const float eps = FLT_EPSILON * 10;
     float A[36], Bc[6];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) A[k] = Vin[k];
+    for (int k = 0; k < 36; ++k) A[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vrow), k));
     const int col = lane % 6;
 #pragma unroll
     for (int i = 0; i < 6; ++i) Bc[i] = (i == col) ? 1.0f : 0.0f;

@@ -157,23 +157,23 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
         const float* matP = st->matP;
         if (it == 0) {                                         // MO:1786-1808
             LIO_LDS_FENCE();
-            lio_eigen6_sym_lanes(ws->AtA, ws->W, ws->V, lane);  // cv::eigen, MO:1792
-            LIO_LDS_FENCE();
-            if (lane == 0) {
-                for (int k = 0; k < 36; ++k) ws->V2[k] = ws->V[k];
-                deg = 0;
-                for (int i = 5; i >= 0; --i) {
-                    if (ws->W[i] < c.eig_thresh) {
-                        for (int j = 0; j < 6; ++j) ws->V2[i * 6 + j] = 0;
-                        deg = 1;
-                    } else {
-                        break;
-                    }
-                }
-                st->is_degenerate = deg;
+            float Wd[6], vrow;
+            lio_eigen6_sym_lanes(ws->AtA, Wd, vrow, lane);      // cv::eigen, MO:1792
+            // MO:1794-1805: from the smallest eigenvalue up, rows of matV2 are cleared while the eigenvalue is below the threshold
+            bool zr[6];
+            bool z = true;
+#pragma unroll
+            for (int i = 5; i >= 0; --i) { z = z && (Wd[i] < c.eig_thresh); zr[i] = z; }
+            deg = zr[5] ? 1 : 0;
+            if (lane < 36) {
+                const int r = lane / 6;
+                bool zero = zr[0];
+#pragma unroll
+                for (int i = 1; i < 6; ++i) if (r == i) zero = zr[i];
+                ws->V2[lane] = zero ? 0.0f : vrow;
             }
-            LIO_LDS_FENCE();
-            lio_inv6_lu_wave(ws->V, ws->B, lane);              // matV.inv(), MO:1807
+            if (lane == 0) st->is_degenerate = deg;
+            lio_inv6_lu_wave(vrow, ws->B, lane);               // matV.inv(), MO:1807
             LIO_LDS_FENCE();
             lio_gemm6_wave(ws->B, ws->V2, ws->A, lane);        // matP = matV.inv() * matV2, MO:1807
             LIO_LDS_FENCE();
