@@ -659,6 +659,17 @@ def main():
                 pkg.transform_update(p)
                 t3 = time.perf_counter()
                 t_asm += t1 - t0; t_reg += t2 - t1; t_upd += t3 - t2
+            node_pipeline = int(node.profile().pipeline)
+            # the same registrations through the launch loop (one launch per GN iteration), for the comparison
+            loop_node = pkg.ScanToMap(device_id=local_rank, pipeline=1)
+            loop_node.share_map(node)
+            for i in range(3):
+                loop_node.scan2MapOptimization(pcl_scans[i], poses0[i])
+            t0 = time.perf_counter()
+            for i in range(n_lat):
+                loop_node.scan2MapOptimization(pcl_scans[i], poses0[i])
+            t_reg_loop = time.perf_counter() - t0
+            loop_node.close()
             map_rec = to_records([map_xyz], 32)
             t_set = 0.0
             for i in range(8):
@@ -670,7 +681,8 @@ def main():
                 "transform_update": 1e3 * t_upd / n_lat, "total_resident_keyframes": 1e3 * (t_asm + t_reg + t_upd) / n_lat,
                 "set_map_from_host_instead": 1e3 * t_set / 8, "total_set_map_from_host": 1e3 * (t_set / 8 + (t_reg + t_upd) / n_lat),
                 "registrations_per_s_single_stream": n_lat / (t_asm + t_reg + t_upd),
-                "scans": n_lat, "note": "one scan per callback as the reference issues it (MO:432-476, MO:1846-1861); Python ctypes caller"}
+                "register_pipeline": node_pipeline, "register_launch_loop_instead": 1e3 * t_reg_loop / n_lat,
+                "scans": n_lat, "note": "one scan per callback as the reference issues it (MO:432-476, MO:1846-1861); Python ctypes caller; register_pipeline 4 = the whole GN loop in one launch (k_s2m_persist), chosen by the default configuration for a lone registration"}
             out["map_assembly"] = {"ms_keyframe_upload_total": 1e3 * t_add, "keyframes": len(kc),
                                    "points_in": int(sum(len(c) for c in kc)), "points_out": int(n_asm)}
             store.close()

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Single-registration latency (lio_s2m_register incl. H2D of the scan and D2H of the result) for the launch-loop options,
+"""Single-registration latency (lio_s2m_register incl. H2D of the scan and D2H of the result) for the launch-loop options
+(cfg.pipeline = 1: eager launches with a lookahead, hipGraph chunks) and the one-launch loop (cfg.pipeline = 4; what the default
+configuration picks for a lone registration); the number in brackets is the pipeline the library reports,
 against the 200-keyframe map of the bench case when its cache is given:  python tools/latency_sweep.py [case.npz]"""
 import importlib, os, sys, time
 import numpy as np
@@ -17,10 +19,10 @@ else:
     case = synth.make_case("hdl64", n_keyframes=60, n_queries=16)
     qs, map_xyz = case["queries"], case["map"]
 print(f"# lio_s2m_register, hdl64 scans N_s ~ {np.mean([len(q['scan']) for q in qs]):.0f} vs N_m = {len(map_xyz)}, incl. H2D of the scan and D2H of the result")
-for name, cfg in [("eager look=1", dict(lookahead=1)), ("eager look=2", dict(lookahead=2)), ("eager look=3", dict(lookahead=3)),
-                  ("graph 3", dict(use_graph=1, graph_iters=3)), ("graph 4", dict(use_graph=1, graph_iters=4)),
-                  ("graph 6", dict(use_graph=1, graph_iters=6)), ("graph 8", dict(use_graph=1, graph_iters=8)),
-                  ("one launch", dict(pipeline=4))]:
+for name, cfg in [("eager look=1", dict(pipeline=1, lookahead=1)), ("eager look=2", dict(pipeline=1, lookahead=2)), ("eager look=3", dict(pipeline=1, lookahead=3)),
+                  ("graph 3", dict(pipeline=1, use_graph=1, graph_iters=3)), ("graph 4", dict(pipeline=1, use_graph=1, graph_iters=4)),
+                  ("graph 6", dict(pipeline=1, use_graph=1, graph_iters=6)), ("graph 8", dict(pipeline=1, use_graph=1, graph_iters=8)),
+                  ("one launch", dict(pipeline=4)), ("default cfg", dict())]:
     s2m = pkg.ScanToMap(**cfg)
     s2m.set_map(map_xyz)
     for q in qs[:4]:
@@ -33,5 +35,6 @@ for name, cfg in [("eager look=1", dict(lookahead=1)), ("eager look=2", dict(loo
             _, res, _ = s2m.scan2MapOptimization(q["scan"], q["pose_init"])
             iters.append(res.iters)
     dt = 1e3 * (time.perf_counter() - t) / (reps * len(qs))
-    print(f"{name:14s} {dt:.3f} ms per registration (mean GN iterations {np.mean(iters):.2f}, {1e3 * dt / np.mean(iters):.1f} us per iteration all included)")
+    name = name + f" [{s2m.profile().pipeline}]"
+    print(f"{name:16s} {dt:.3f} ms per registration (mean GN iterations {np.mean(iters):.2f}, {1e3 * dt / np.mean(iters):.1f} us per iteration all included)")
     s2m.close()
