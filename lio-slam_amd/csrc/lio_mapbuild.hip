@@ -16,6 +16,9 @@
 
 int lio_fail_ext(int code, const char* what, hipError_t e);                    // liogpu_api.hip
 int lio_s2m_set_map_device_xyzi(lio_s2m_handle* h, const float4* d_xyzi, size_t n);   // liogpu_api.hip
+int lio_s2m_set_map_device_bbox(lio_s2m_handle* h, const float4* d_xyzi, size_t n, const float box[6]);
+hipStream_t lio_s2m_stream_of(lio_s2m_handle* h);
+bool lio_s2m_takes_device_map(const lio_s2m_handle* h);
 
 #define HIPCHK(expr)                                                              \
     do {                                                                          \
@@ -286,8 +289,35 @@ __global__ void k_xyzi4_to_aos(const float4* __restrict__ src, int n, unsigned c
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = 1.0f; o[4] = v.w;
 }
 
+// Grow-only device buffer owned by a keyframe store: the workspace of lio_assemble_map_resident, kept from one call to
+// the next so that nothing has to be waited for before the call returns (a pool temporary is recycled on return).
+struct LioKeep {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t alloc(size_t bytes)
+    {
+        if (!bytes) bytes = 16;
+        if (p && bytes <= cap) return hipSuccess;
+        if (p) {                                          // growing: whoever still reads the old block must be done
+            hipError_t e = hipDeviceSynchronize();
+            if (e != hipSuccess) return e;
+            e = hipFree(p);
+            p = nullptr; cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        const size_t want = bytes + bytes / 4 + 256;
+        const hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() { return (T*)p; }
+};
+
 namespace {
 typedef LioTemp Buf;         // temporaries come from the recycling pool (lio_pool.h)
+
+template <class B> struct LioVoxWs { B bbox, key_of, count, start, rank, tiles, tmp, list, large; };
 
 float ord2f(unsigned u)
 {
@@ -299,21 +329,26 @@ float ord2f(unsigned u)
 
 // K7 on a device-resident float4 cloud.  *d_out receives a freshly allocated device array.
 // Returns LIO_OK, or 1 when PCL would pass the cloud through (voxel index overflow).
-int voxel_grid_device(const float4* d_in, int n, float leaf, Buf& out, int* n_out, hipStream_t s)
+// `ws`: the temporaries; `wait`: block until the result is complete (required when ws is made of pool temporaries, which
+// are recycled when the caller returns); `box` (optional) receives min[3], max[3] of the INPUT cloud, a box around the output.
+template <class B>
+int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out, hipStream_t s, LioVoxWs<B>& ws, bool wait, float* box)
 {
     *n_out = 0;
+    if (box) for (int a = 0; a < 6; ++a) box[a] = 0.0f;
     if (n == 0) return LIO_OK;
-    Buf bbox;
+    B& bbox = ws.bbox;
     HIPCHK(bbox.alloc(6 * sizeof(unsigned)));
     const unsigned init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
     HIPCHK(hipMemcpyAsync(bbox.p, init, sizeof(init), hipMemcpyHostToDevice, s));
     int nbb = (n + 1023) / 1024; if (nbb > 512) nbb = 512; if (nbb < 1) nbb = 1;
-    hipLaunchKernelGGL(k_vox_bbox, dim3(nbb), dim3(256), 0, s, d_in, n, bbox.as<unsigned>());
+    hipLaunchKernelGGL(k_vox_bbox, dim3(nbb), dim3(256), 0, s, d_in, n, bbox.template as<unsigned>());
     unsigned hb[6];
     HIPCHK(hipMemcpyAsync(hb, bbox.p, sizeof(hb), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     float mn[3], mx[3];
     for (int a = 0; a < 3; ++a) { mn[a] = ord2f(hb[a]); mx[a] = ord2f(hb[3 + a]); }
+    if (box) for (int a = 0; a < 3; ++a) { box[a] = mn[a]; box[3 + a] = mx[a]; }
     const float inv = 1.0f / leaf;
     const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1,
                     dz = (long long)((mx[2] - mn[2]) * inv) + 1;
@@ -332,7 +367,7 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, Buf& out, int* n_ou
     const long long n_keys_ll = (long long)d0 * d1 * d2;
     if (n_keys_ll > (1LL << 29)) return lio_fail_ext(LIO_ERR_CAPACITY, "voxel grid has more than 2^29 voxels", hipSuccess);
     g.n_keys = (int)n_keys_ll;
-    Buf key_of, count, start, rank, tiles, tmp, list;
+    B &key_of = ws.key_of, &count = ws.count, &start = ws.start, &rank = ws.rank, &tiles = ws.tiles, &tmp = ws.tmp, &list = ws.list;
     HIPCHK(key_of.alloc(sizeof(int) * (size_t)n));
     HIPCHK(tmp.alloc(sizeof(int) * (size_t)n));
     HIPCHK(count.alloc(sizeof(int) * (size_t)g.n_keys));
@@ -341,33 +376,39 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, Buf& out, int* n_ou
     HIPCHK(tiles.alloc(sizeof(int) * ((size_t)lio_scan_tiles(g.n_keys) + 1)));
     const int nb = (n + 255) / 256, nk = (g.n_keys + 255) / 256;
     HIPCHK(hipMemsetAsync(count.p, 0, sizeof(int) * (size_t)g.n_keys, s));
-    hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, g, d_in, n, key_of.as<int>(), count.as<int>());
-    lio_launch_exclusive_scan(count.as<int>(), g.n_keys, tiles.as<int>(), start.as<int>(), s);
+    hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, g, d_in, n, key_of.template as<int>(), count.template as<int>());
+    lio_launch_exclusive_scan(count.template as<int>(), g.n_keys, tiles.template as<int>(), start.template as<int>(), s);
     HIPCHK(hipMemsetAsync(count.p, 0, sizeof(int) * (size_t)g.n_keys, s));
-    hipLaunchKernelGGL(k_vox_scatter, dim3(nb), dim3(256), 0, s, key_of.as<int>(), n, start.as<int>(), count.as<int>(), tmp.as<int>());
-    hipLaunchKernelGGL(k_vox_flags, dim3(nk), dim3(256), 0, s, start.as<int>(), g.n_keys, count.as<int>());
-    lio_launch_exclusive_scan(count.as<int>(), g.n_keys, tiles.as<int>(), rank.as<int>(), s);
+    hipLaunchKernelGGL(k_vox_scatter, dim3(nb), dim3(256), 0, s, key_of.template as<int>(), n, start.template as<int>(), count.template as<int>(), tmp.template as<int>());
+    hipLaunchKernelGGL(k_vox_flags, dim3(nk), dim3(256), 0, s, start.template as<int>(), g.n_keys, count.template as<int>());
+    lio_launch_exclusive_scan(count.template as<int>(), g.n_keys, tiles.template as<int>(), rank.template as<int>(), s);
     int no = 0;
-    HIPCHK(hipMemcpyAsync(&no, rank.as<int>() + g.n_keys, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&no, rank.template as<int>() + g.n_keys, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(list.alloc(sizeof(int) * (size_t)(no ? no : 1)));
     HIPCHK(out.alloc(sizeof(float4) * (size_t)(no ? no : 1)));
-    Buf large;                                               // [0] = count, [1..] = output slots of crowded voxels
+    B& large = ws.large;                                     // [0] = count, [1..] = output slots of crowded voxels
     HIPCHK(large.alloc(sizeof(int) * ((size_t)no + 1)));
     HIPCHK(hipMemsetAsync(large.p, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_vox_list, dim3(nk), dim3(256), 0, s, start.as<int>(), rank.as<int>(), g.n_keys, list.as<int>());
+    hipLaunchKernelGGL(k_vox_list, dim3(nk), dim3(256), 0, s, start.template as<int>(), rank.template as<int>(), g.n_keys, list.template as<int>());
     if (no) {
-        hipLaunchKernelGGL(k_vox_centroid_small, dim3((no + 255) / 256), dim3(256), 0, s, d_in, start.as<int>(), list.as<int>(), no,
-                           tmp.as<int>(), out.as<float4>());
-        hipLaunchKernelGGL(k_vox_centroid, dim3((no + 3) / 4), dim3(256), 0, s, d_in, start.as<int>(), list.as<int>(), no,
-                           tmp.as<int>(), out.as<float4>(), large.as<int>() + 1, large.as<int>());
-        hipLaunchKernelGGL(k_vox_centroid_large, dim3(no < 1024 ? no : 1024), dim3(256), 0, s, d_in, start.as<int>(), list.as<int>(),
-                           tmp.as<int>(), out.as<float4>(), large.as<int>() + 1, large.as<int>());
+        hipLaunchKernelGGL(k_vox_centroid_small, dim3((no + 255) / 256), dim3(256), 0, s, d_in, start.template as<int>(), list.template as<int>(), no,
+                           tmp.template as<int>(), out.template as<float4>());
+        hipLaunchKernelGGL(k_vox_centroid, dim3((no + 3) / 4), dim3(256), 0, s, d_in, start.template as<int>(), list.template as<int>(), no,
+                           tmp.template as<int>(), out.template as<float4>(), large.template as<int>() + 1, large.template as<int>());
+        hipLaunchKernelGGL(k_vox_centroid_large, dim3(no < 1024 ? no : 1024), dim3(256), 0, s, d_in, start.template as<int>(), list.template as<int>(),
+                           tmp.template as<int>(), out.template as<float4>(), large.template as<int>() + 1, large.template as<int>());
     }
-    HIPCHK(hipStreamSynchronize(s));       // temporaries are freed on return
+    if (wait) HIPCHK(hipStreamSynchronize(s));       // (pool temporaries are recycled when the caller returns)
     HIPCHK(hipGetLastError());
     *n_out = no;
     return LIO_OK;
+}
+
+int voxel_grid_device(const float4* d_in, int n, float leaf, Buf& out, int* n_out, hipStream_t s)
+{
+    LioVoxWs<Buf> ws;
+    return voxel_grid_device<Buf>(d_in, n, leaf, out, n_out, s, ws, true, nullptr);
 }
 
 int copy_out(const float4* d_pts, int n, void* out, size_t out_stride, hipStream_t s)
@@ -427,6 +468,11 @@ struct lio_kf_store {
     float4* d_pts = nullptr;
     size_t cap = 0, used = 0;
     std::vector<size_t> off, cnt;
+    // workspace of lio_assemble_map_resident when the map is installed in a handle (kept between calls)
+    LioVoxWs<LioKeep> vws;
+    LioKeep world, ds, d_kf, d_poses, d_chunks;
+    std::vector<LioKfDesc> v_kf;
+    std::vector<int2> v_chunks;
 };
 
 extern "C" int lio_kf_store_create(int32_t device_id, lio_kf_store** out)
@@ -444,7 +490,11 @@ extern "C" void lio_kf_store_destroy(lio_kf_store* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device_id);
+    (void)hipDeviceSynchronize();
     if (s->d_pts) (void)hipFree(s->d_pts);
+    LioKeep* keep[] = { &s->vws.bbox, &s->vws.key_of, &s->vws.count, &s->vws.start, &s->vws.rank, &s->vws.tiles, &s->vws.tmp, &s->vws.list,
+                        &s->vws.large, &s->world, &s->ds, &s->d_kf, &s->d_poses, &s->d_chunks };
+    for (LioKeep* k : keep) k->release();
     delete s;
 }
 
@@ -569,6 +619,40 @@ extern "C" int lio_assemble_map_resident(lio_s2m_handle* h, lio_kf_store* st, in
     }
     if (total > 0x7fffffffull - 1024) return lio_fail_ext(LIO_ERR_CAPACITY, "too many points", hipSuccess);
     if (n_out) *n_out = 0;
+    if (lio_s2m_takes_device_map(h)) {
+        // The node path (MO:1556-1588 straight into the resident map of `h`): everything on the handle's stream, the
+        // temporaries kept in the store, the map's grid laid over the bounding box the voxel filter measured anyway, and no
+        // wait at the end -- the registration that follows is ordered behind the build.  The two waits left are the voxel
+        // filter's (bounding box, then the number of occupied voxels: both size what comes next).
+        hipStream_t s = lio_s2m_stream_of(h);
+        st->v_kf.swap(kf);                 // (host arrays of the asynchronous copies live in the store)
+        st->v_chunks.swap(chunks);
+        HIPCHK(st->world.alloc(total * sizeof(float4)));
+        HIPCHK(st->d_kf.alloc(sizeof(LioKfDesc) * (size_t)(n_sel ? n_sel : 1)));
+        HIPCHK(st->d_poses.alloc(sizeof(float) * 6 * (size_t)(n_sel ? n_sel : 1)));
+        HIPCHK(st->d_chunks.alloc(sizeof(int2) * (st->v_chunks.size() ? st->v_chunks.size() : 1)));
+        if (n_sel) {
+            HIPCHK(hipMemcpyAsync(st->d_kf.p, st->v_kf.data(), sizeof(LioKfDesc) * (size_t)n_sel, hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(st->d_poses.p, poses, sizeof(float) * 6 * (size_t)n_sel, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_kf_transforms, dim3((n_sel + 63) / 64), dim3(64), 0, s, st->d_kf.as<LioKfDesc>(), st->d_poses.as<float>(), n_sel);
+        }
+        if (!st->v_chunks.empty()) {
+            HIPCHK(hipMemcpyAsync(st->d_chunks.p, st->v_chunks.data(), sizeof(int2) * st->v_chunks.size(), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_transform_clouds, dim3((unsigned)st->v_chunks.size()), dim3(256), 0, s, st->d_pts,
+                               st->d_kf.as<LioKfDesc>(), st->d_chunks.as<int2>(), st->world.as<float4>());
+        }
+        int no = 0;
+        float box[6];
+        rc = voxel_grid_device<LioKeep>(st->world.as<float4>(), (int)total, leaf, st->ds, &no, s, st->vws, false, box);
+        if (rc < 0) return rc;
+        // (`poses` was consumed by the voxel filter's first wait, which follows its copy on the same stream)
+        const int rc3 = lio_s2m_set_map_device_bbox(h, st->ds.as<float4>(), (size_t)no, box);
+        if (rc3 != LIO_OK) return rc3;
+        const int rc2 = copy_out(st->ds.as<float4>(), no, out, out_stride, s);
+        if (rc2 < 0) return rc2;
+        if (n_out) *n_out = (size_t)no;
+        return rc;
+    }
     hipStream_t s = nullptr;
     Buf d_kf, d_poses, d_chunks, world, ds;
     HIPCHK(world.alloc(total * sizeof(float4)));
@@ -589,7 +673,7 @@ extern "C" int lio_assemble_map_resident(lio_s2m_handle* h, lio_kf_store* st, in
     int no = 0;
     rc = voxel_grid_device(world.as<float4>(), (int)total, leaf, ds, &no, s);
     if (rc < 0) return rc;
-    if (h) {                               // install as the resident local map without leaving the device
+    if (h) {                               // (a multi-device or map-sharing handle: through the generic path)
         const int rc3 = lio_s2m_set_map_device_xyzi(h, ds.as<float4>(), (size_t)no);
         if (rc3 != LIO_OK) return rc3;
     }

@@ -175,6 +175,8 @@ struct lio_s2m_handle {
     // profiling
     hipEvent_t ev_beg[LIO_MAX_ITERS] = {}, ev_end[LIO_MAX_ITERS] = {}, ev_chk[LIO_MAX_ITERS] = {};
     hipEvent_t ev_map[2] = {};
+    hipEvent_t ev_mapl[2] = {};        // asynchronous map installation (lio_s2m_set_map_device_bbox): build time resolved on demand; [1] = "map ready"
+    bool map_timing_pending = false;
     int* h_active = nullptr;          // pinned: active-scan count after each launch
     bool ev_ok = false;
     lio_s2m_profile prof{};
@@ -287,6 +289,8 @@ static int lio_s2m_init_resources(lio_s2m_handle* h)
     HIPCHK(hipHostMalloc((void**)&h->h_active, sizeof(int) * LIO_MAX_ITERS, hipHostMallocDefault));
     HIPCHK(hipEventCreate(&h->ev_map[0]));
     HIPCHK(hipEventCreate(&h->ev_map[1]));
+    HIPCHK(hipEventCreate(&h->ev_mapl[0]));
+    HIPCHK(hipEventCreate(&h->ev_mapl[1]));
     h->ev_ok = true;
     HIPCHK(hipMalloc((void**)&h->d_bbox, 6 * sizeof(unsigned)));
     HIPCHK(hipMalloc((void**)&h->d_active, sizeof(int)));
@@ -387,6 +391,8 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
     if (h->h_scan_bbox) (void)hipHostFree(h->h_scan_bbox);
     if (h->ev_map[0]) (void)hipEventDestroy(h->ev_map[0]);
     if (h->ev_map[1]) (void)hipEventDestroy(h->ev_map[1]);
+    if (h->ev_mapl[0]) (void)hipEventDestroy(h->ev_mapl[0]);
+    if (h->ev_mapl[1]) (void)hipEventDestroy(h->ev_mapl[1]);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -430,20 +436,27 @@ static int lio_map_reserve(lio_s2m_handle* h, size_t n)
 }
 
 // common tail: d_mx/d_my/d_mz/d_map4 hold the n map points -> bounding box, grid, neighbourhood rows
-static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock::time_point t0)
+// `box` (optional): min[3], max[3] of a box known to contain every map point -- the grid is laid over it without a bounding-box
+// pass and its read-back (any enclosing box gives an exact search; the grid is only a few cells larger) -- and the call
+// returns with the build still in flight on the handle's stream: the registrations that follow are ordered behind it,
+// sharers wait for ev_mapl[1], the build time is resolved when the profile is read.
+static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock::time_point t0, const float* box = nullptr)
 {
     const size_t nn = n ? n : 1;
-    unsigned init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
-    HIPCHK(hipMemcpyAsync(h->d_bbox, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
-    if (n) lio_launch_map_bbox(h->d_mx, h->d_my, h->d_mz, (int)n, h->d_bbox, h->stream);
-    unsigned hb[6];
-    HIPCHK(hipMemcpyAsync(hb, h->d_bbox, sizeof(hb), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    auto t1 = std::chrono::steady_clock::now();
-
     float mn[3], mx[3];
-    bool empty = (n == 0) || hb[0] == 0xffffffffu;
-    for (int a = 0; a < 3; ++a) { mn[a] = empty ? 0.0f : lio_ord2f(hb[a]); mx[a] = empty ? 0.0f : lio_ord2f(hb[3 + a]); }
+    if (box) {
+        for (int a = 0; a < 3; ++a) { mn[a] = n ? box[a] : 0.0f; mx[a] = n ? box[3 + a] : 0.0f; }
+    } else {
+        unsigned init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+        HIPCHK(hipMemcpyAsync(h->d_bbox, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+        if (n) lio_launch_map_bbox(h->d_mx, h->d_my, h->d_mz, (int)n, h->d_bbox, h->stream);
+        unsigned hb[6];
+        HIPCHK(hipMemcpyAsync(hb, h->d_bbox, sizeof(hb), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const bool empty = (n == 0) || hb[0] == 0xffffffffu;
+        for (int a = 0; a < 3; ++a) { mn[a] = empty ? 0.0f : lio_ord2f(hb[a]); mx[a] = empty ? 0.0f : lio_ord2f(hb[3 + a]); }
+    }
+    auto t1 = std::chrono::steady_clock::now();
 
     // cell edge = gate radius (+0.1 %) / k; the candidate scan visits (2k+1)^3 cells
     int kdiv = h->cfg.cell_div;
@@ -471,7 +484,7 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
     HIPCHK(lio_grow(&h->d_nbr_pts, &h->cap_nbr_pts, nn * (size_t)((2 * g.k + 1) * (2 * g.k + 1)) + LIO_ROW_ALIGN * (size_t)g.ny * g.nz + 4 * LIO_ROW_ALIGN, 1.05));
     HIPCHK(lio_grow(&h->d_tile_sums, &h->cap_tile_sums, (size_t)lio_scan_tiles(g.n_cells) + 1));
 
-    HIPCHK(hipEventRecord(h->ev_map[0], h->stream));
+    HIPCHK(hipEventRecord(box ? h->ev_mapl[0] : h->ev_map[0], h->stream));
     if (n) {
         lio_launch_map_build(g, h->d_mx, h->d_my, h->d_mz, (int)n, h->d_cell_of, h->d_cell_count,
                              h->d_cell_start, h->d_tile_sums, h->d_sorted, h->d_nbr_start, h->d_nbr_pts, h->stream);
@@ -479,12 +492,19 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
         HIPCHK(hipMemsetAsync(h->d_cell_start, 0, sizeof(int) * ((size_t)g.n_cells + 1), h->stream));
         HIPCHK(hipMemsetAsync(h->d_nbr_start, 0, sizeof(int) * ((size_t)g.n_cells + 1), h->stream));
     }
-    HIPCHK(hipEventRecord(h->ev_map[1], h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipEventRecord(box ? h->ev_mapl[1] : h->ev_map[1], h->stream));
     HIPCHK(hipGetLastError());
-    float ms = 0.0f;
-    HIPCHK(hipEventElapsedTime(&ms, h->ev_map[0], h->ev_map[1]));
-    h->prof.map_build_ms = ms;
+    if (box) {
+        h->map_timing_pending = true;
+    } else {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_map[0], h->ev_map[1]));
+        h->prof.map_build_ms = ms;
+        h->map_timing_pending = false;
+        HIPCHK(hipEventRecord(h->ev_mapl[1], h->stream));            // "map ready" for sharers (already true)
+    }
     h->prof.map_upload_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
     h->prof.n_map = (int64_t)n;
     h->prof.n_cells = g.n_cells;
@@ -604,6 +624,27 @@ int lio_s2m_set_map_device_xyzi(lio_s2m_handle* h, const float4* d_xyzi, size_t 
     lio_launch_xyzi4_to_soa(d_xyzi, (int)n, h->d_mx, h->d_my, h->d_mz, h->d_map4, h->stream);
     return lio_map_finish(h, n, t0);
 }
+
+// The same for a producer that ran on THIS handle's stream (lio_assemble_map_resident) and knows a box around the
+// points: no device-wide wait, no bounding-box pass, no wait at the end (see lio_map_finish).
+int lio_s2m_set_map_device_bbox(lio_s2m_handle* h, const float4* d_xyzi, size_t n, const float box[6])
+{
+    if (!h || !box) return lio_fail(LIO_ERR_ARG, "null argument");
+    if (h->multi || h->map_src) return lio_fail(LIO_ERR_ARG, "this handle cannot take a device-resident map");
+    if (n >= (1ull << 25)) return lio_fail(LIO_ERR_CAPACITY, "map too large ((2k+1)^2 x n records must fit a 31-bit offset)");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();
+    auto t0 = std::chrono::steady_clock::now();
+    h->has_map = false;
+    h->run_pending = false;
+    int rc = lio_map_reserve(h, n);
+    if (rc != LIO_OK) return rc;
+    lio_launch_xyzi4_to_soa(d_xyzi, (int)n, h->d_mx, h->d_my, h->d_mz, h->d_map4, h->stream);
+    return lio_map_finish(h, n, t0, box);
+}
+
+hipStream_t lio_s2m_stream_of(lio_s2m_handle* h) { return h ? h->stream : nullptr; }
+bool lio_s2m_takes_device_map(const lio_s2m_handle* h) { return h && !h->multi && !h->map_src; }
 
 extern "C" int lio_s2m_set_global_grid(lio_s2m_handle* h, const float origin[3], const int32_t dims[3])
 {
@@ -1291,13 +1332,14 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     if (!lio_map_of(h)->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
     if (h->n_scans < 1 || !h->poses_set) return lio_fail(LIO_ERR_ARG, "batch_upload and batch_set_poses first");
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     if (h->map_src && h->map_epoch != h->map_src->map_epoch) {      // the shared map was replaced since the last run
         h->map_epoch = h->map_src->map_epoch;
         h->cache_dirty = true;
         h->graph_dirty = true;
+        HIPCHK(hipStreamWaitEvent(h->stream, h->map_src->ev_mapl[1], 0));   // (its build may still be in flight on the owner's stream)
     }
-    HIPCHK(hipSetDevice(h->cfg.device_id));
-    (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->pose_in_state, h->c, h->d_active, h->stream);
     h->pose_in_state = false;          // (d_poses holds the guess from now on)
     if (h->split && h->cfg.profile && h->d_split_stats)
@@ -1813,6 +1855,14 @@ extern "C" int lio_s2m_get_profile(lio_s2m_handle* h, lio_s2m_profile* out)
 {
     if (!h || !out) return lio_fail(LIO_ERR_ARG, "null argument");
     if (h->multi) h->prof.n_map = (int64_t)h->n_map;
+    if (h->map_timing_pending) {
+        HIPCHK(hipSetDevice(h->cfg.device_id));
+        HIPCHK(hipEventSynchronize(h->ev_mapl[1]));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, h->ev_mapl[0], h->ev_mapl[1]));
+        h->prof.map_build_ms = ms;
+        h->map_timing_pending = false;
+    }
     *out = h->prof;
     return LIO_OK;
 }
