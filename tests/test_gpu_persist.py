@@ -102,3 +102,57 @@ def test_batches_that_do_not_fit_fall_back_to_the_launch_loop(pkg, small_case):
         outs.append(p)
         s.close()
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_one_launch_loops_on_concurrent_streams(pkg, small_case):
+    """Three host threads, three handles, three streams at once: two issue lone registrations (one-launch loops, whose
+    workgroups wait for each other at their scan's barrier) while the third keeps the device busy with a large batch
+    through the launch loop.  Every wait is bounded, so the worst case would be LIO_ERR_HIP, never a hang; the results
+    must be the ones a quiet device gives."""
+    import threading
+    qs = small_case["queries"]
+    owner = pkg.ScanToMap()
+    owner.set_map(small_case["map"])
+    want = [owner.scan2MapOptimization(q["scan"], q["pose_init"])[0] for q in qs]
+    big_scans = [qs[k % len(qs)]["scan"] for k in range(48)]
+    big_poses = np.stack([qs[k % len(qs)]["pose_init"] for k in range(48)])
+    owner.batch_upload(big_scans); owner.batch_set_poses(big_poses); owner.batch_run()
+    big_want, _ = owner.batch_results()
+    assert owner.profile().pipeline == 1                   # 48 scans x ~20 workgroups: too many for one launch
+    errors, got = [], {0: [], 1: []}
+
+    def lone(idx):
+        try:
+            h = pkg.ScanToMap()
+            h.share_map(owner)
+            for rep in range(25):
+                for q in qs:
+                    got[idx].append(h.scan2MapOptimization(q["scan"], q["pose_init"])[0])
+            assert h.profile().pipeline == 4
+            h.close()
+        except Exception as e:                              # noqa: BLE001
+            errors.append(e)
+
+    def batch():
+        try:
+            h = pkg.ScanToMap(sort_scan=2)
+            h.share_map(owner)
+            for rep in range(12):
+                h.batch_upload(big_scans); h.batch_set_poses(big_poses); h.batch_run()
+                p, _ = h.batch_results()
+                np.testing.assert_array_equal(p, big_want)
+            h.close()
+        except Exception as e:                              # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=lone, args=(0,)), threading.Thread(target=lone, args=(1,)), threading.Thread(target=batch)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for idx in (0, 1):
+        assert len(got[idx]) == 25 * len(qs)
+        for k, p in enumerate(got[idx]):
+            np.testing.assert_array_equal(p, want[k % len(qs)])
+    owner.close()
