@@ -66,7 +66,7 @@ void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stag
 void lio_launch_split_iteration(const LioSplitParams& S, int n_blocks, hipStream_t s);
 void lio_launch_iterate_cert(const LioSplitParams& S, int n_blocks, hipStream_t s);
 void lio_launch_persist(const LioIterParams& P, int n_blocks, unsigned* gen, unsigned epoch, const unsigned char* stage, size_t stride,
-                        hipStream_t s);
+                        int n_scans, unsigned* spec, double* spec_sums, const float* poses0, hipStream_t s);
 void lio_launch_pack_summary(const LioScanState* st, int n_scans, float* out, hipStream_t s);
 void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
                       int* n_active, hipStream_t s);

@@ -11,6 +11,15 @@
 // the scan's state.  Every poll loop is bounded: after LIO_PERSIST_SPIN_MAX polls the workgroup leaves with the
 // scan's `done` flag still clear, so every wave reaches an exit whatever happens (the host finds a scan that is not done
 // after the launch and reports LIO_ERR_HIP).
+//
+// Speculation on isDegenerate.  The first solve of a registration carries cv::eigen for isDegenerate / matP (MO:1786-1808),
+// ~36 us of Jacobi rotations that the next pose formally depends on -- but only if a direction IS degenerate.  So the
+// first solve publishes the non-degenerate update right after the QR solve and hands the eigen-decomposition to a helper
+// workgroup (one per scan, behind the association workgroups in the grid), which writes isDegenerate / matP and answers
+// through spec[scan].  Later solves look at the answer: not there yet -> carry on with isDegenerate = 0, unless the step
+// would END the registration, which waits for the answer; "not degenerate" -> nothing to repair; "degenerate" -> roll the
+// scan back to its first solve (saved sums, initial guess) and redo that step the plain way, the iterations in between are
+// discarded.  Results are the launch loop's in every case (tests/test_gpu_persist.py: corridor scenes take the roll-back).
 #include <hip/hip_runtime.h>
 #ifndef LIO_PREFETCH
 #define LIO_PREFETCH 2       // a lone registration runs ONE wave per SIMD: nothing else hides the candidate loads, so two groups are
@@ -24,7 +33,8 @@
 
 namespace {
 
-__global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, unsigned* __restrict__ gen, unsigned epoch, const unsigned char* __restrict__ stage, unsigned stride)
+__global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, unsigned* __restrict__ gen, unsigned epoch, const unsigned char* __restrict__ stage, unsigned stride,
+                   int n_main, unsigned* __restrict__ spec, double* __restrict__ spec_sums, const float* __restrict__ poses0)
 {
     __shared__ __attribute__((aligned(16))) double s_rows[LIO_BLOCK][8];
     __shared__ double s_part[8][28];
@@ -33,6 +43,57 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
     __shared__ int s_ctl;                                  // 0 = next iteration, 1 = the scan is done, 2 = poll timed out
 
     const int wg = blockIdx.x;                             // (no XCD remap: a registration's few workgroups are spread over the XCDs as dealt)
+    if (wg >= n_main) {
+        // ---- helper of scan `wg - n_main`: the eigen-decomposition / inverse / product of the first solve, off the critical path
+        const int scan = wg - n_main;
+        if (threadIdx.x >= 64) return;
+        const int hl = threadIdx.x;
+        LioScanState* hs = &P.state[scan];
+        if (hs->done) return;                              // (refused at init: nothing will ever be asked)
+        unsigned spins = 0;
+        for (;;) {
+            const int v = (int)(__hip_atomic_load(&spec[scan], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch);
+            if (v >= 1) break;                             // asked
+            if (__hip_atomic_load(&hs->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the registration ended without asking
+            if (++spins > LIO_PERSIST_SPIN_MAX * 2u) return;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (hl == 0) {                                     // matAtA as LMOptimization builds it from the sums of the first iteration
+            const double* sm = spec_sums + (size_t)scan * LIO_SUMS;
+            int p = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int b = a; b < 6; ++b) {
+                    const float v = (float)__hip_atomic_load(sm + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ++p;
+                    s_ws.AtA[a * 6 + b] = v; s_ws.AtA[b * 6 + a] = v;
+                }
+        }
+        LIO_LDS_FENCE();
+        float Wd[6], vrow;
+        lio_eigen6_sym_lanes(s_ws.AtA, Wd, vrow, hl);       // cv::eigen, MO:1792
+        bool zr[6];
+        bool z = true;
+#pragma unroll
+        for (int i = 5; i >= 0; --i) { z = z && (Wd[i] < P.c.eig_thresh); zr[i] = z; }     // MO:1794-1805
+        const int deg = zr[5] ? 1 : 0;
+        if (hl < 36) {
+            const int r = hl / 6;
+            bool zero = zr[0];
+#pragma unroll
+            for (int i = 1; i < 6; ++i) if (r == i) zero = zr[i];
+            s_ws.V2[hl] = zero ? 0.0f : vrow;
+        }
+        lio_inv6_lu_wave(vrow, s_ws.B, hl);                 // matV.inv(), MO:1807
+        LIO_LDS_FENCE();
+        lio_gemm6_wave(s_ws.B, s_ws.V2, s_ws.A, hl);        // matP = matV.inv() * matV2
+        LIO_LDS_FENCE();
+        if (hl < 36) hs->matP[hl] = s_ws.A[hl];
+        if (hl == 0) hs->is_degenerate = deg;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (hl == 0) __hip_atomic_store(&spec[scan], epoch + 2u + (unsigned)deg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     const LioBlockDesc bd = P.blocks[wg];
     LioScanState* st = &P.state[bd.scan];
     const LioGrid g = P.grid;
@@ -185,12 +246,61 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
                 long long t_s = stamp ? (long long)wall_clock64() : 0;
                 const int so = it == 0 ? 8 : 11;
                 if (stamp) { stamp[so] += t_s - t_prev; if (it) stamp[14] += 1; }
-                lio_gn_step(st, s_sum, P.c, &s_ws, P.n_active, lane);
+                bool ask = false, lost = false;
+                // a discarded pass must not leave a recorded association behind: speculate only when none can be recorded after pass 0
+                const bool may_spec = spec != nullptr && (P.rec_flag == nullptr || P.c.record_iter <= 0);
+                const int st_it = st->iter;                                  // (0 also after a roll-back, which settles the speculation first)
+                int sp = spec ? (int)(__hip_atomic_load(&spec[bd.scan], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) : 0;
+                if (sp < 0 || sp > 4) sp = 0;                                // 0 none, 1 asked, 2 answer: not degenerate, 3 answer: degenerate, 4 settled
+                const bool first_spec = st_it == 0 && sp == 0 && may_spec;
+                bool plain = true;
+                if (first_spec || sp == 1) {
+                    // first solve: the non-degenerate update now, the eigen-decomposition by the helper; later solves without an
+                    // answer yet: carry on as "not degenerate".  Either way a step that would END the registration is held back.
+                    if (lio_gn_step(st, s_sum, P.c, &s_ws, P.n_active, lane, 0, first_spec, true) == 2) {
+                        if (!first_spec) {                                   // wait for the answer, then decide below
+                            unsigned spins = 0;
+                            while (sp == 1) {
+                                sp = (int)(__hip_atomic_load(&spec[bd.scan], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch);
+                                if (++spins > LIO_PERSIST_SPIN_MAX) { lost = true; break; }
+                                __builtin_amdgcn_s_sleep(4);
+                            }
+                        }
+                    } else {
+                        plain = false;                                       // committed (speculatively)
+                        if (first_spec) {
+                            if (lane < 28) __hip_atomic_store(spec_sums + (size_t)bd.scan * LIO_SUMS + lane, s_sum[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ask = true;
+                        }
+                    }
+                }
+                if (plain && !lost) {
+                    if (sp == 2 || sp == 3) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the helper's isDegenerate / matP
+                    if (sp == 3) {
+                        // a degenerate direction: back to the first solve.  Initial guess, iteration counter and the records of the
+                        // discarded passes are restored; st->T stays (it becomes Tp, which is what the search bounds of the last pass refer to)
+                        if (lane == 0) {
+                            for (int k = 0; k < 6; ++k) st->pose[k] = poses0[bd.scan * 6 + k];
+                            for (int j = 1; j <= st_it && j < 32; ++j) {
+                                st->n_corr_iter[j] = 0;
+                                for (int k = 0; k < 6; ++k) st->pose_iter[j][k] = 0.0f;
+                            }
+                            st->iter = 0;
+                            st->converged = 0;
+                        }
+                        if (lane < 28) s_sum[lane] = __hip_atomic_load(spec_sums + (size_t)bd.scan * LIO_SUMS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    }
+                    lio_gn_step(st, s_sum, P.c, &s_ws, P.n_active, lane);        // the plain step: settled, answered, never asked, or ending
+                    if (sp == 3 && lane == 0) __hip_atomic_store(&spec[bd.scan], epoch + 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 if (stamp) { const long long t_ = (long long)wall_clock64(); stamp[so + 1] += t_ - t_s; t_s = t_; }
                 // publish: the state written above becomes visible to the other XCDs before the generation number does
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 if (stamp) { const long long t_ = (long long)wall_clock64(); stamp[so + 2] += t_ - t_s; }
-                if (lane == 0) __hip_atomic_store(&gen[bd.scan], epoch + (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0 && ask) __hip_atomic_store(&spec[bd.scan], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0 && !lost) __hip_atomic_store(&gen[bd.scan], epoch + (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (last) LIO_TICK(5);
             // per-scan barrier: wait for this iteration's solve (bounded)
@@ -210,7 +320,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // the solver's writes to *st, not stale cache lines
         if (s_ctl == 2) return;
         if (__hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // MO:1857-1858 / MO:1848, workgroup-uniform
-        if (it + 1 >= 32) return;                                          // (LIO_MAX_ITERS; max_iters <= 32 sets done before this)
+        if (it + 1 >= 2 * 32 + 2) return;                                  // (LIO_MAX_ITERS passes, at most doubled by one roll-back; `done` ends the loop before this)
         __syncthreads();                                                   // s_ctl / s_part are rewritten by the next trip
         LIO_TICK(7);
     }
@@ -219,11 +329,16 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
 
 }  // namespace
 
-// `epoch`: a number that grows by at least 64 from one launch on these buffers to the next (the generation numbers of a run
+// `epoch`: a number that grows by at least 128 from one launch on these buffers to the next (the generation numbers of a run
 // are epoch + 1 .. epoch + 32, compared modulo 2^32), so nothing has to be cleared between runs.
+// `epoch`: a number that grows by at least 128 from one launch on these buffers to the next (generation numbers and
+// speculation states of a run are epoch + small numbers, compared modulo 2^32), so nothing has to be cleared between runs.
+// spec != nullptr: n_scans helper workgroups follow the n_blocks association workgroups (see "Speculation" above).
 void lio_launch_persist(const LioIterParams& P, int n_blocks, unsigned* gen, unsigned epoch, const unsigned char* stage, size_t stride,
-                        hipStream_t s)
+                        int n_scans, unsigned* spec, double* spec_sums, const float* poses0, hipStream_t s)
 {
     if (n_blocks <= 0) return;
-    hipLaunchKernelGGL(k_s2m_persist, dim3(n_blocks), dim3(LIO_BLOCK), 0, s, P, gen, epoch, stage, (unsigned)stride);
+    const int n_help = spec ? n_scans : 0;
+    hipLaunchKernelGGL(k_s2m_persist, dim3(n_blocks + n_help), dim3(LIO_BLOCK), 0, s, P, gen, epoch, stage, (unsigned)stride,
+                       n_blocks, spec, spec_sums, poses0);
 }

@@ -117,8 +117,15 @@ LIO_DEV float lio_sqdist(float ax, float ay, float az, float bx, float by, float
 // wave (lio_eigen6_sym_wave, lio_gemm6_wave), and so are the six fp64 sines / cosines of the next transform
 // (lio_pose_to_transform_wave).  This step ends every Gauss-Newton launch and is the critical path of a lone
 // registration ("one-launch loop").
-__device__ static void lio_gn_step(LioScanState* st, const double* sums, const LioConsts& c, LioSolveWs* ws,
-                                   int* n_active, int lane)
+// The last three arguments serve the one-launch loop's speculation (lio_persist.hip) and default to the plain step:
+//   deg_override >= 0  use this isDegenerate instead of the scan's stored one (iterations > 0);
+//   skip_eigen         iteration 0 without the eigen-decomposition: isDegenerate / matP are left alone, the update is
+//                      the non-degenerate one (a helper workgroup computes them meanwhile);
+//   hold_if_done       if this step would end the registration (converged, last iteration, too few correspondences),
+//                      change nothing that depends on that decision and return 2 -- the caller settles the speculation first.
+// Returns 0, or 2 when held.
+__device__ static int lio_gn_step(LioScanState* st, const double* sums, const LioConsts& c, LioSolveWs* ws,
+                                  int* n_active, int lane, int deg_override = -1, bool skip_eigen = false, bool hold_if_done = false)
 {
     const int it = st->iter;
     const int nc = (int)sums[LIO_SUM_NC];
@@ -136,7 +143,7 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
     if (solve) {
         int deg = 0;
         if (lane == 0) {
-            deg = st->is_degenerate;
+            deg = deg_override >= 0 ? deg_override : st->is_degenerate;
             float A[36];
             int p = 0;
 #pragma unroll
@@ -155,7 +162,7 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
             lio_solve6_qr_reg(A, X);                           // MO:1784
         }
         const float* matP = st->matP;
-        if (it == 0) {                                         // MO:1786-1808
+        if (it == 0 && !skip_eigen) {                          // MO:1786-1808
             LIO_LDS_FENCE();
             float Wd[6], vrow;
             lio_eigen6_sym_lanes(ws->AtA, Wd, vrow, lane);      // cv::eigen, MO:1792
@@ -200,6 +207,11 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
     }
 
     int done = 0;
+    if (hold_if_done) {
+        int d = 0;
+        if (lane == 0) d = ((conv && !c.force_all) || it + 1 >= c.max_iters || nc < c.min_corr) ? 1 : 0;
+        if (__shfl(d, 0)) return 2;
+    }
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) st->pose[k] = pose[k];
@@ -235,6 +247,7 @@ __device__ static void lio_gn_step(LioScanState* st, const double* sums, const L
             for (int k = 0; k < 6; ++k) st->trig[k] = trn[k];
         }
     }
+    return 0;
 }
 
 // ---- candidate scan, global-memory form -----------------------------------

@@ -118,8 +118,9 @@ struct lio_s2m_handle {
     bool split = false;               // the resident batch runs k_s2m_cert / _scan / _fit instead of k_s2m_iterate
     bool certk = false;               // the resident batch runs k_s2m_iterate_cert (cfg.pipeline = 3)
     // one-launch loop (cfg.pipeline = 4, k_s2m_persist): per-scan generation numbers
-    unsigned* d_gen = nullptr; size_t cap_gen = 0;
-    unsigned gen_epoch = 0;           // grows by 64 per run: generation numbers are never cleared
+    unsigned* d_gen = nullptr; size_t cap_gen = 0;     // [2][cap_gen / 2]: generation numbers, then the speculation states
+    double* d_spec_sums = nullptr; size_t cap_spec_sums = 0;   // sums of the first solve of every scan (roll-back of the speculation)
+    unsigned gen_epoch = 0;           // grows by 128 per run: generation numbers are never cleared
     int n_cu = 0;                     // compute units of the device: every workgroup of a one-launch loop must be resident
     bool run_persist = false;
     bool soa_valid = true;            // d_sx/d_sy/d_sz hold the resident batch (false: a one-launch batch still only staged as records)
@@ -379,7 +380,7 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
                      h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
                      h->d_nn_cache, h->d_summary, h->d_groups, h->d_cache_idx, h->d_cache_q, h->d_pt_flag,
-                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox, h->d_block_box, h->d_blk_skip, h->d_plane, h->d_plane_state, h->d_gen };
+                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox, h->d_block_box, h->d_blk_skip, h->d_plane, h->d_plane_state, h->d_gen, h->d_spec_sums };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < LIO_MAX_ITERS; ++i) {               // (a handle whose creation failed half-way holds nulls)
         if (h->ev_beg[i]) (void)hipEventDestroy(h->ev_beg[i]);
@@ -796,7 +797,7 @@ static bool lio_persist_eligible(const lio_s2m_handle* h)
     if (h->cfg.pipeline == 4) limit = h->n_cu;
     else if (h->cfg.pipeline == 0 && !h->cfg.use_graph && h->cfg.profile != 2) limit = h->n_cu / 4;
     return limit > 0 && !h->split && !h->certk && !h->cfg.use_lds && h->ppt == 1 && h->shard.axis < 0 &&
-           h->block_world == 1 && h->n_blocks > 0 && h->n_blocks <= limit;
+           h->block_world == 1 && h->n_blocks > 0 && h->n_blocks + h->n_scans <= limit;      // (+ one helper workgroup per scan)
 }
 
 // The SoA copy of the resident batch, for the paths that read it, if the upload skipped it.
@@ -1416,7 +1417,8 @@ static int lio_run_continue(lio_s2m_handle* h, bool blocking)
         if (prof) HIPCHK(hipEventRecord(h->ev_beg[u], h->stream));
         if (h->run_persist) {
             lio_launch_persist(h->run_P, h->n_blocks, h->d_gen, h->gen_epoch, h->soa_valid ? nullptr : h->last_stage + h->last_xyz_off,
-                               h->last_stride, h->stream);
+                               h->last_stride, h->n_scans, getenv("LIO_NO_SPEC") ? nullptr : h->d_gen + h->n_scans, h->d_spec_sums, h->d_poses,
+                               h->stream);
         } else if (h->run_graph) HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
         else lio_launch_gn(h, h->run_P, Pc);
         if (prof) HIPCHK(hipEventRecord(h->ev_end[u], h->stream));
@@ -1495,12 +1497,13 @@ extern "C" int lio_s2m_batch_run(lio_s2m_handle* h)
         if (h->cfg.lookahead < 0) look = 0;              // a chunk already is a run-ahead of `chunk` launches
     }
     if (h->run_persist) {
-        if ((size_t)h->n_scans > h->cap_gen || !h->d_gen) {
-            HIPCHK(lio_grow(&h->d_gen, &h->cap_gen, (size_t)h->n_scans));
-            HIPCHK(hipMemsetAsync(h->d_gen, 0, h->cap_gen * sizeof(unsigned), h->stream));   // (fresh generation numbers)
+        if ((size_t)h->n_scans * 2 > h->cap_gen || !h->d_gen) {
+            HIPCHK(lio_grow(&h->d_gen, &h->cap_gen, (size_t)h->n_scans * 2));
+            HIPCHK(hipMemsetAsync(h->d_gen, 0, h->cap_gen * sizeof(unsigned), h->stream));   // (fresh generation numbers / speculation states)
             h->gen_epoch = 0;
         }
-        h->gen_epoch += 64;
+        HIPCHK(lio_grow(&h->d_spec_sums, &h->cap_spec_sums, (size_t)h->n_scans * LIO_SUMS));
+        h->gen_epoch += 128;
         chunk = h->cfg.max_iters;                        // one unit = the whole loop
     }
     h->run_graph = graph;

@@ -156,3 +156,34 @@ def test_one_launch_loops_on_concurrent_streams(pkg, small_case):
         for k, p in enumerate(got[idx]):
             np.testing.assert_array_equal(p, want[k % len(qs)])
     owner.close()
+
+
+@pytest.mark.parametrize("max_iters", [1, 2, 3, 30])
+@pytest.mark.parametrize("force", [0, 1])
+def test_speculation_on_isdegenerate_and_its_roll_back(pkg, synth, small_case, max_iters, force):
+    """The one-launch loop publishes the non-degenerate update of the first solve before isDegenerate is known (a helper
+    workgroup runs cv::eigen meanwhile) and rolls the scan back when the answer is "degenerate".  A handle alternates between a
+    corridor (degenerate: roll-back) and a street scene (not degenerate), so the isDegenerate / matP left by the previous
+    registration (members MO:176-177) are stale every time; loop lengths 1-3 hit the "step ends the registration" rule at
+    the first, second and third solve.  Everything observable equals the launch loop's."""
+    cor = synth.make_case("vlp16", n_keyframes=5, seed=3, kind="corridor", device="cpu")
+    seq = [(cor["map"], cor["queries"][0]), (small_case["map"], small_case["queries"][0]),
+           (small_case["map"], small_case["queries"][1]), (cor["map"], cor["queries"][0]), (cor["map"], cor["queries"][0])]
+    outs = []
+    for pipe in (1, 4):
+        h = pkg.ScanToMap(pipeline=pipe, max_iters=max_iters, force_all_iters=force)
+        rows = []
+        for m, q in seq:
+            h.set_map(m)
+            pose, res, rc = h.scan2MapOptimization(q["scan"], q["pose_init"])
+            rows.append((pose, res, rc))
+        assert h.profile().pipeline == pipe
+        h.close()
+        outs.append(rows)
+    degs = []
+    for (pa, ra, rca), (pb, rb, rcb) in zip(*outs):
+        assert rca == rcb
+        np.testing.assert_array_equal(pa, pb)
+        _same_result(ra, rb)
+        degs.append(rb.is_degenerate)
+    assert degs == [1, 0, 0, 1, 1]
