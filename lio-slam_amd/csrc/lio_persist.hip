@@ -229,14 +229,14 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
                 if (lane < 28) {
                     const double* base_p = P.partials + (size_t)bd.scan * P.max_blk * LIO_SUMS + lane;
                     double v = 0.0;
-                    for (int b = 0; b < bd.n_blk; b += 8) {
-                        double t[8];
+                    for (int b = 0; b < bd.n_blk; b += 32) {        // 32 write-through loads in flight (a lone scan has ~26 chunks), summed in chunk order
+                        double t[32];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u)
+                        for (int u = 0; u < 32; ++u)
                             t[u] = __hip_atomic_load(base_p + (size_t)min(b + u, bd.n_blk - 1) * LIO_SUMS,
                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) v += (b + u < bd.n_blk) ? t[u] : 0.0;
+                        for (int u = 0; u < 32; ++u) v += (b + u < bd.n_blk) ? t[u] : 0.0;
                     }
                     s_sum[lane] = v;
                 }
