@@ -91,7 +91,7 @@ typedef struct lio_s2m_config {
                                 0 = auto: one launch per iteration (k_s2m_iterate), or -- for a batch of at most a quarter
                                 of a workgroup per compute unit, e.g. a lone registration, unless use_graph or profile = 2
                                 is set -- the whole loop as ONE launch (k_s2m_persist: per-scan barrier between
-                                iterations; 0.21 against 0.25 ms per registration on MI355X); 1 = always one launch per
+                                iterations; 0.17 against 0.25 ms per registration on MI355X); 1 = always one launch per
                                 iteration; 4 = the one-launch loop for every batch of at most one workgroup per compute
                                 unit; 2 = split: neighbour certificate / candidate scan / fit as three launches; 3 = the
                                 per-iteration launch with the certificate inside (k_s2m_iterate_cert); 2 measured slower

@@ -786,7 +786,7 @@ static int lio_build_groups(lio_s2m_handle* h, const std::vector<LioBlockDesc>& 
 // ------------------------------------------------------------------- batch
 // The whole Gauss-Newton loop as one launch (k_s2m_persist, lio_persist.hip): possible when every workgroup of the batch is
 // resident at once and the batch uses nothing but the default surf association; measured faster than the launch loop
-// for every batch that fits (0.21 against 0.25 ms for a lone registration).  cfg.pipeline = 4 takes
+// for every batch that fits (0.17 against 0.25 ms for a lone registration).  cfg.pipeline = 4 takes
 // it for up to one workgroup per compute unit; auto (0) for up to a quarter of that -- a lone registration is ~26
 // workgroups --, so that several handles doing so at the same time still fit the device together (a workgroup that waits
 // at its scan's barrier keeps its slot; the polls are bounded, a launch that cannot make progress ends with LIO_ERR_HIP).
