@@ -312,57 +312,19 @@ LIO_DEV bool lio_corner_assoc(const float m[5][3], float x0, float y0, float z0,
 // Executed by ONE lane per scan per iteration (the serial tail of the GN
 // step).  All working storage is a caller-provided LDS workspace so that the
 // association kernel needs no scratch memory.
-struct LioSolveWs {
-    float A[36];      // destroyed by the factorisations
-    float B[36];      // inverse / scratch
-    float V[36];
-    float V2[36];
-    float AtA[36];
-    float AtB[6], X[6], X2[6], W[6], vl[6], hf[6];
-    int   indR[6], indC[6];
+struct LioSolveWs {      // LDS working storage of lio_gn_step
+    float A[36];      // product matV.inv() * matV2 (matP)
+    float B[36];      // matV.inv()
+    float V2[36];     // eigenvectors with the degenerate rows cleared
+    float AtA[36];    // matAtA of the first iteration (input of the eigen-decomposition)
+    float X[6], X2[6];
 };
 
 // cv::solve(AtA, AtB, X, DECOMP_QR), MO:1784 (OpenCV hal::QR32f: Householder
 // with unit-norm reflectors, then back substitution; singular -> X = 0).
-// A (6x6 row-major) is destroyed, b is replaced by the solution.
-__device__ static int lio_solve6_qr(float* A, float* b, float* vl, float* hf)
-{
-    const float eps = FLT_EPSILON * 10;
-    for (int l = 0; l < 6; ++l) {
-        const int vs = 6 - l;
-        float vnorm = 0.0f;
-        for (int i = 0; i < vs; ++i) { vl[i] = A[(l + i) * 6 + l]; vnorm += vl[i] * vl[i]; }
-        const float tmpv = vl[0];
-        const float sg = vl[0] >= 0.0f ? 1.0f : -1.0f;
-        vl[0] = vl[0] + sg * sqrtf(vnorm);
-        vnorm = sqrtf(vnorm + vl[0] * vl[0] - tmpv * tmpv);
-        for (int i = 0; i < vs; ++i) vl[i] /= vnorm;
-        for (int j = l; j < 6; ++j) {
-            float va = 0.0f;
-            for (int i = l; i < 6; ++i) va += vl[i - l] * A[i * 6 + j];
-            for (int i = l; i < 6; ++i) A[i * 6 + j] -= 2 * vl[i - l] * va;
-        }
-        hf[l] = vl[0] * vl[0];
-        for (int i = 1; i < vs; ++i) A[(l + i) * 6 + l] = vl[i] / vl[0];
-    }
-    for (int l = 0; l < 6; ++l) {
-        vl[0] = 1.0f;
-        for (int j = 1; j < 6 - l; ++j) vl[j] = A[(j + l) * 6 + l];
-        float vb = 0.0f;
-        for (int i = l; i < 6; ++i) vb += vl[i - l] * b[i];
-        for (int i = l; i < 6; ++i) b[i] -= 2 * vl[i - l] * vb * hf[l];
-    }
-    for (int i = 5; i >= 0; --i) {
-        for (int j = 5; j > i; --j) b[i] -= b[j] * A[i * 6 + j];
-        if (fabsf(A[i * 6 + i]) < eps) { for (int p = 0; p < 6; ++p) b[p] = 0.0f; return 0; }
-        b[i] /= A[i * 6 + i];
-    }
-    return 1;
-}
-
-// The same solve on PRIVATE arrays with every loop unrolled, so that the 6x6 system lives in registers: identical
-// operations in identical order (the solve sits at the end of every Gauss-Newton launch, on the critical path of a lone
-// registration; walking it through LDS cost ~10 us per iteration).
+// A (6x6 row-major) is destroyed, b is replaced by the solution.  PRIVATE arrays, every loop unrolled, so that the 6x6
+// system lives in registers (the solve sits at the end of every Gauss-Newton launch, on the critical path of a lone
+// registration; an earlier form that walked it through LDS cost ~10 us per iteration).
 __device__ static __forceinline__ int lio_solve6_qr_reg(float (&A)[36], float (&b)[6])
 {
     const float eps = FLT_EPSILON * 10;
@@ -420,190 +382,13 @@ __device__ static __forceinline__ int lio_solve6_qr_reg(float (&A)[36], float (&
     return 1;
 }
 
-// cv::eigen(matAtA, matE, matV), MO:1792 (OpenCV JacobiImpl_: largest
-// off-diagonal pivot tracked per row/column; eigenvalues sorted descending,
-// eigenvectors as rows).  A is destroyed.
-__device__ static void lio_eigen6_sym(float* A, float* W, float* V, int* indR, int* indC)
-{
-    const float eps = FLT_EPSILON;
-    int i, j, k, m;
-    float mv;
-    for (i = 0; i < 6; ++i) for (j = 0; j < 6; ++j) V[i * 6 + j] = (i == j) ? 1.0f : 0.0f;
-    for (k = 0; k < 6; ++k) {
-        W[k] = A[k * 6 + k];
-        if (k < 5) {
-            for (m = k + 1, mv = fabsf(A[k * 6 + m]), i = k + 2; i < 6; ++i) {
-                const float val = fabsf(A[k * 6 + i]);
-                if (mv < val) { mv = val; m = i; }
-            }
-            indR[k] = m;
-        }
-        if (k > 0) {
-            for (m = 0, mv = fabsf(A[k]), i = 1; i < k; ++i) {
-                const float val = fabsf(A[i * 6 + k]);
-                if (mv < val) { mv = val; m = i; }
-            }
-            indC[k] = m;
-        }
-    }
-    for (int iters = 0; iters < 6 * 6 * 30; ++iters) {
-        for (k = 0, mv = fabsf(A[indR[0]]), i = 1; i < 5; ++i) {
-            const float val = fabsf(A[i * 6 + indR[i]]);
-            if (mv < val) { mv = val; k = i; }
-        }
-        int l = indR[k];
-        for (i = 1; i < 6; ++i) {
-            const float val = fabsf(A[indC[i] * 6 + i]);
-            if (mv < val) { mv = val; k = indC[i]; l = i; }
-        }
-        const float p = A[k * 6 + l];
-        if (fabsf(p) <= eps) break;
-        const float y = (float)((W[l] - W[k]) * 0.5);
-        float t = fabsf(y) + lio_cv_hypot(p, y);
-        float s = lio_cv_hypot(p, t);
-        const float c = t / s;
-        s = p / s; t = (p / t) * p;
-        if (y < 0) { s = -s; t = -t; }
-        A[k * 6 + l] = 0;
-        W[k] -= t;
-        W[l] += t;
-        float a0, b0;
-#define LIO_ROT(v0, v1) do { a0 = (v0); b0 = (v1); (v0) = a0 * c - b0 * s; (v1) = a0 * s + b0 * c; } while (0)
-        for (i = 0; i < k; ++i)     LIO_ROT(A[i * 6 + k], A[i * 6 + l]);
-        for (i = k + 1; i < l; ++i) LIO_ROT(A[k * 6 + i], A[i * 6 + l]);
-        for (i = l + 1; i < 6; ++i) LIO_ROT(A[k * 6 + i], A[l * 6 + i]);
-        for (i = 0; i < 6; ++i)     LIO_ROT(V[k * 6 + i], V[l * 6 + i]);
-#undef LIO_ROT
-        for (j = 0; j < 2; ++j) {
-            const int idx = j == 0 ? k : l;
-            if (idx < 5) {
-                for (m = idx + 1, mv = fabsf(A[idx * 6 + m]), i = idx + 2; i < 6; ++i) {
-                    const float val = fabsf(A[idx * 6 + i]);
-                    if (mv < val) { mv = val; m = i; }
-                }
-                indR[idx] = m;
-            }
-            if (idx > 0) {
-                for (m = 0, mv = fabsf(A[idx]), i = 1; i < idx; ++i) {
-                    const float val = fabsf(A[i * 6 + idx]);
-                    if (mv < val) { mv = val; m = i; }
-                }
-                indC[idx] = m;
-            }
-        }
-    }
-    for (k = 0; k < 5; ++k) {
-        m = k;
-        for (i = k + 1; i < 6; ++i) if (W[m] < W[i]) m = i;
-        if (k != m) {
-            float t = W[m]; W[m] = W[k]; W[k] = t;
-            for (i = 0; i < 6; ++i) { t = V[m * 6 + i]; V[m * 6 + i] = V[k * 6 + i]; V[k * 6 + i] = t; }
-        }
-    }
-}
-
-// The same decomposition executed by one whole wave (the serial version costs ~240 k cycles of dependent
-// LDS round trips and sits at the very end of the first launch of every registration).  Every
-// floating-point operation and every comparison is the one the serial code performs; only independent
-// ones run side by side:
-//   pivot     lanes 0-4 hold the row candidates |A[i][indR[i]]|, lanes 5-9 the column candidates
-//             |A[indC[i]][i]| in the order the serial scan visits them; the first lane holding the maximum
-//             is the serial scan's strict-`<` winner;
-//   rotation  lanes 0-5 rotate the (up to four) off-diagonal pairs, lanes 8-13 the six eigenvector pairs,
-//             lane 6 updates the pivot and the two diagonal entries;
-//   trackers  lanes 0-3 recompute indR[k], indC[k], indR[l], indC[l].
-// All lanes of the wave must call it; A, W, V, indR, indC are in LDS.
 #define LIO_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-__device__ static void lio_eigen6_sym_wave(float* A, float* W, float* V, int* indR, int* indC, int lane)
-{
-    const float eps = FLT_EPSILON;
-    if (lane < 36) V[lane] = (lane / 6 == lane % 6) ? 1.0f : 0.0f;
-    if (lane < 6) W[lane] = A[lane * 7];
-    if (lane < 5) {                                          // indR[k], k = lane
-        int m = lane + 1;
-        float mv = fabsf(A[lane * 6 + m]);
-        for (int i = lane + 2; i < 6; ++i) { const float val = fabsf(A[lane * 6 + i]); if (mv < val) { mv = val; m = i; } }
-        indR[lane] = m;
-    } else if (lane >= 9 && lane < 14) {                     // indC[k], k = lane - 8 in 1..5
-        const int k = lane - 8;
-        int m = 0;
-        float mv = fabsf(A[k]);
-        for (int i = 1; i < k; ++i) { const float val = fabsf(A[i * 6 + k]); if (mv < val) { mv = val; m = i; } }
-        indC[k] = m;
-    }
-    LIO_LDS_FENCE();
-    for (int iters = 0; iters < 6 * 6 * 30; ++iters) {
-        float v = -1.0f;
-        int ck = 0, cl = 0;
-        if (lane < 5) { ck = lane; cl = indR[lane]; v = fabsf(A[ck * 6 + cl]); }
-        else if (lane < 10) { cl = lane - 4; ck = indC[cl]; v = fabsf(A[ck * 6 + cl]); }
-        float mx = v;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        const unsigned long long win = __ballot(lane < 10 && v == mx) & 0x3ffull;
-        const int j = win ? __builtin_ctzll(win) : 0;
-        const int k = __shfl(ck, j), l = __shfl(cl, j);
-        const float p = A[k * 6 + l];
-        if (fabsf(p) <= eps) break;                          // wave-uniform
-        const float wk = W[k], wl = W[l];
-        const float y = (float)((wl - wk) * 0.5);
-        float t = fabsf(y) + lio_cv_hypot(p, y);
-        float s = lio_cv_hypot(p, t);
-        const float c = t / s;
-        s = p / s; t = (p / t) * p;
-        if (y < 0) { s = -s; t = -t; }
-        LIO_LDS_FENCE();                                     // every lane has read before anyone writes
-        if (lane < 6) {
-            const int i = lane;
-            if (i != k && i != l) {
-                const int a0i = i < k ? i * 6 + k : k * 6 + i, a1i = i < l ? i * 6 + l : l * 6 + i;
-                const float a0 = A[a0i], b0 = A[a1i];
-                A[a0i] = a0 * c - b0 * s; A[a1i] = a0 * s + b0 * c;
-            }
-        } else if (lane == 6) {
-            A[k * 6 + l] = 0;
-            W[k] = wk - t;
-            W[l] = wl + t;
-        } else if (lane >= 8 && lane < 14) {
-            const int i = lane - 8;
-            const float a0 = V[k * 6 + i], b0 = V[l * 6 + i];
-            V[k * 6 + i] = a0 * c - b0 * s; V[l * 6 + i] = a0 * s + b0 * c;
-        }
-        LIO_LDS_FENCE();
-        if (lane < 4) {
-            const int idx = lane < 2 ? k : l;
-            if ((lane & 1) == 0) {
-                if (idx < 5) {
-                    int m = idx + 1;
-                    float mv = fabsf(A[idx * 6 + m]);
-                    for (int i = idx + 2; i < 6; ++i) { const float val = fabsf(A[idx * 6 + i]); if (mv < val) { mv = val; m = i; } }
-                    indR[idx] = m;
-                }
-            } else if (idx > 0) {
-                int m = 0;
-                float mv = fabsf(A[idx]);
-                for (int i = 1; i < idx; ++i) { const float val = fabsf(A[i * 6 + idx]); if (mv < val) { mv = val; m = i; } }
-                indC[idx] = m;
-            }
-        }
-        LIO_LDS_FENCE();
-    }
-    if (lane == 0) {                                         // descending selection sort, eigenvectors are rows
-        for (int k = 0; k < 5; ++k) {
-            int m = k;
-            for (int i = k + 1; i < 6; ++i) if (W[m] < W[i]) m = i;
-            if (k != m) {
-                float t = W[m]; W[m] = W[k]; W[k] = t;
-                for (int i = 0; i < 6; ++i) { t = V[m * 6 + i]; V[m * 6 + i] = V[k * 6 + i]; V[k * 6 + i] = t; }
-            }
-        }
-    }
-    LIO_LDS_FENCE();
-}
 
-// The same decomposition with the matrices in REGISTERS, one element per lane (lane e < 36 holds A[e/6][e%6] and
-// V[e/6][e%6], lanes 0..5 also W[lane], indR[lane], indC[lane]): no LDS round trips and no fences inside the loop, which a
-// lone registration waits for ~34 times (the LDS form costs ~1.1 us per rotation).  Element reads with a wave-uniform
+// cv::eigen(matAtA, matE, matV), MO:1792 (OpenCV JacobiImpl_: largest off-diagonal pivot tracked per row / column through
+// indR / indC; eigenvalues sorted descending, eigenvectors as rows), executed by one wave with the matrices in
+// REGISTERS, one element per lane (lane e < 36 holds A[e/6][e%6] and V[e/6][e%6], lanes 0..5 also W[lane], indR[lane],
+// indC[lane]): no LDS round trips and no fences inside the loop (~34 rotations per registration; a form that kept the
+// matrices in LDS cost 1.7 us per rotation, this one 1.06).  Element reads with a wave-uniform
 // index are v_readlane, per-lane indices go through ds_bpermute; every floating-point operation and comparison is
 // the serial code's:
 //   pivot     lanes 0-4 fetch |A[i][indR[i]]|, lanes 1-5 |A[indC[i]][i]|; the serial scan (rows 0..4, then columns 1..5,
@@ -728,40 +513,10 @@ __device__ static void lio_gemm6_wave(const float* A, const float* B, float* C, 
     }
 }
 
-// matV.inv(), MO:1807 (OpenCV hal::LU32f on [A | I], partial pivoting;
-// singular -> zero matrix).  A is destroyed, B receives the inverse.
-__device__ static int lio_inv6_lu(float* A, float* B)
-{
-    const float eps = FLT_EPSILON * 10;
-    int i, j, k;
-    for (i = 0; i < 6; ++i) for (j = 0; j < 6; ++j) B[i * 6 + j] = (i == j) ? 1.0f : 0.0f;
-    for (i = 0; i < 6; ++i) {
-        k = i;
-        for (j = i + 1; j < 6; ++j) if (fabsf(A[j * 6 + i]) > fabsf(A[k * 6 + i])) k = j;
-        if (fabsf(A[k * 6 + i]) < eps) { for (j = 0; j < 36; ++j) B[j] = 0.0f; return 0; }
-        if (k != i) {
-            for (j = i; j < 6; ++j) { const float t = A[i * 6 + j]; A[i * 6 + j] = A[k * 6 + j]; A[k * 6 + j] = t; }
-            for (j = 0; j < 6; ++j) { const float t = B[i * 6 + j]; B[i * 6 + j] = B[k * 6 + j]; B[k * 6 + j] = t; }
-        }
-        const float d = -1 / A[i * 6 + i];
-        for (j = i + 1; j < 6; ++j) {
-            const float alpha = A[j * 6 + i] * d;
-            for (k = i + 1; k < 6; ++k) A[j * 6 + k] += alpha * A[i * 6 + k];
-            for (k = 0; k < 6; ++k) B[j * 6 + k] += alpha * B[i * 6 + k];
-        }
-    }
-    for (i = 5; i >= 0; --i)
-        for (j = 0; j < 6; ++j) {
-            float s = B[i * 6 + j];
-            for (k = i + 1; k < 6; ++k) s -= A[i * 6 + k] * B[k * 6 + j];
-            B[i * 6 + j] = s / A[i * 6 + i];
-        }
-    return 1;
-}
-
-// The same inverse by a wave, ALL lanes calling: lane j (0..5) carries column j of [A | I] through the elimination with A
-// in registers (every lane eliminates its own copy of A: the pivot decisions are wave-uniform); the operations on
-// each element are the serial code's, in its order.  The matrix arrives one element per lane (vrow of lane e < 36 =
+// matV.inv(), MO:1807 (OpenCV hal::LU32f on [A | I], partial pivoting; singular -> zero matrix) by a wave, ALL lanes
+// calling: lane j (0..5) carries column j of [A | I] through the elimination with A in registers (every lane eliminates
+// its own copy of A: the pivot decisions are wave-uniform); the operations on each element are the serial code's
+// (oracle/lio_oracle.c), in its order.  The matrix arrives one element per lane (vrow of lane e < 36 =
 // element (e/6, e%6)); lanes 0..5 write B (LDS).
 __device__ static void lio_inv6_lu_wave(float vrow, float* B, int lane)
 {
