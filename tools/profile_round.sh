@@ -26,8 +26,5 @@ pass WRITE_SIZE WRITE_SIZE
 pass SQ SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 pass TCC TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 pass SQ2 SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE GRBM_TA_BUSY
-# single registrations (the node path): kernel durations against the gaps between them
-rm -rf /tmp/prof/lat
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof/lat -o lat -- python tools/latency_sweep.py $CASE > $OUT/latency_sweep.txt 2>/tmp/lat.err
-python tools/single_scan_trace.py /tmp/prof/lat >> $OUT/latency_sweep.txt
+# (single registrations: tools/latency_sweep.py, tools/register_trace.py, tools/persist_clock.py, tools/small_batch_sweep.py)
 grep -h "k_s2m_iterate" $OUT/rocprofv3_kernel_stats.txt $OUT/pmc_*.txt | cut -c1-200
