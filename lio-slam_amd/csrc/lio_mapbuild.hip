@@ -107,6 +107,76 @@ __global__ void k_vox_bbox(const float4* __restrict__ p, int n, unsigned* __rest
     }
 }
 
+// K6 with getMinMax3D folded in: the bounding box of the transformed cloud (what the voxel filter starts with) is
+// accumulated while the points are written, one set of atomics per workgroup -- no separate pass over the 1.3 M points.
+__global__ __launch_bounds__(256) void k_transform_clouds_bbox(const float4* __restrict__ store, const LioKfDesc* __restrict__ kf,
+                                                               const int2* __restrict__ chunks /* (kf, first) */,
+                                                               float4* __restrict__ dst, float* __restrict__ blk_box /* [grid][6] */)
+{
+    const int2 c = chunks[blockIdx.x];
+    const LioKfDesc d = kf[c.x];
+    const int li = c.y + (int)threadIdx.x;
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    if (li < d.n) {
+        const float4 p = store[d.src + li];
+        const float4 q = make_float4(d.T[0] * p.x + d.T[1] * p.y + d.T[2]  * p.z + d.T[3],
+                                     d.T[4] * p.x + d.T[5] * p.y + d.T[6]  * p.z + d.T[7],
+                                     d.T[8] * p.x + d.T[9] * p.y + d.T[10] * p.z + d.T[11], p.w);   // MO:861-864
+        dst[d.first + li] = q;
+        mn[0] = mx[0] = q.x; mn[1] = mx[1] = q.y; mn[2] = mx[2] = q.z;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    __shared__ float s_mn[4][3], s_mx[4][3];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float lo = s_mn[0][a], hi = s_mx[0][a];
+        for (int w = 1; w < 4; ++w) { lo = fminf(lo, s_mn[w][a]); hi = fmaxf(hi, s_mx[w][a]); }
+        blk_box[(size_t)blockIdx.x * 6 + a] = lo;            // (+inf / -inf for an empty chunk)
+        blk_box[(size_t)blockIdx.x * 6 + 3 + a] = hi;
+    }
+}
+
+// the per-workgroup boxes of k_transform_clouds_bbox -> one box, in k_vox_bbox's order-preserving encoding (one workgroup;
+// ~5 000 workgroups hammering six words with atomics cost 124 us, this costs 3)
+__global__ __launch_bounds__(256) void k_bbox_reduce(const float* __restrict__ blk_box, int n_blk, unsigned* __restrict__ bbox)
+{
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int i = threadIdx.x; i < n_blk; i += 256)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], blk_box[(size_t)i * 6 + a]); mx[a] = fmaxf(mx[a], blk_box[(size_t)i * 6 + 3 + a]); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off));
+        }
+    __shared__ float s_mn[4][3], s_mx[4][3];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_mn[wave][a] = mn[a]; s_mx[wave][a] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float lo = s_mn[0][a], hi = s_mx[0][a];
+        for (int w = 1; w < 4; ++w) { lo = fminf(lo, s_mn[w][a]); hi = fmaxf(hi, s_mx[w][a]); }
+        bbox[a] = lo <= hi ? lio_f2ord2(lo) : 0xffffffffu;
+        bbox[3 + a] = lo <= hi ? lio_f2ord2(hi) : 0u;
+    }
+}
+
 struct LioVoxGrid { float inv; int min_b0, min_b1, min_b2, mul1, mul2, n_keys; };
 
 // voxel index of pcl::VoxelGrid: x-fastest over the cloud's own bounding box
@@ -137,6 +207,78 @@ __global__ void k_vox_flags(const int* __restrict__ start, int n_keys, int* __re
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_keys) flag[k] = (start[k + 1] > start[k]) ? 1 : 0;
+}
+
+// Two exclusive scans of the per-voxel counts in one pass: start[k] = points in voxels < k, rank[k] = OCCUPIED voxels < k
+// (the output slot of voxel k).  Both sums travel in one 64-bit word (low: points < 2^31, high: voxels < 2^29).
+#define LIO_VS_ITEMS 16
+#define LIO_VS_TILE (256 * LIO_VS_ITEMS)
+__device__ __forceinline__ unsigned long long vox_block_exscan(unsigned long long v, unsigned long long* total, unsigned long long* s_wave)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const unsigned long long q = s_wave[w]; if (w < wave) wave_off += q; tot += q; }
+    __syncthreads();
+    *total = tot;
+    return wave_off + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_vox_scan_tiles(const int* __restrict__ count, int n, unsigned long long* __restrict__ tile_sums)
+{
+    __shared__ unsigned long long s_wave[4];
+    const int base = blockIdx.x * LIO_VS_TILE + threadIdx.x * LIO_VS_ITEMS;
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int k = 0; k < LIO_VS_ITEMS; ++k)
+        if (base + k < n) { const int c = count[base + k]; acc += (unsigned long long)(unsigned)c + (c > 0 ? (1ull << 32) : 0ull); }
+    unsigned long long tot;
+    vox_block_exscan(acc, &tot, s_wave);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_vox_scan_offsets(unsigned long long* __restrict__ tile_sums, int n_tiles)
+{
+    __shared__ unsigned long long s_wave[4];
+    unsigned long long carry = 0;
+    for (int b = 0; b < n_tiles; b += 256) {
+        const int i = b + threadIdx.x;
+        const unsigned long long v = i < n_tiles ? tile_sums[i] : 0ull;
+        unsigned long long tot;
+        const unsigned long long ex = vox_block_exscan(v, &tot, s_wave);
+        if (i < n_tiles) tile_sums[i] = carry + ex;
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_vox_scan_apply(const int* __restrict__ count, int n, const unsigned long long* __restrict__ tile_offsets,
+                                                        int* __restrict__ start /* n+1 */, int* __restrict__ rank /* n+1 */)
+{
+    __shared__ unsigned long long s_wave[4];
+    const int base = blockIdx.x * LIO_VS_TILE + threadIdx.x * LIO_VS_ITEMS;
+    int v[LIO_VS_ITEMS];
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int k = 0; k < LIO_VS_ITEMS; ++k) {
+        v[k] = (base + k < n) ? count[base + k] : 0;
+        acc += (unsigned long long)(unsigned)v[k] + (v[k] > 0 ? (1ull << 32) : 0ull);
+    }
+    unsigned long long tot;
+    unsigned long long run = tile_offsets[blockIdx.x] + vox_block_exscan(acc, &tot, s_wave);
+#pragma unroll
+    for (int k = 0; k < LIO_VS_ITEMS; ++k) {
+        if (base + k < n) { start[base + k] = (int)(unsigned)run; rank[base + k] = (int)(run >> 32); }
+        run += (unsigned long long)(unsigned)v[k] + (v[k] > 0 ? (1ull << 32) : 0ull);
+        if (base + k == n - 1) { start[n] = (int)(unsigned)run; rank[n] = (int)(run >> 32); }
+    }
 }
 
 __global__ void k_vox_list(const int* __restrict__ start, const int* __restrict__ rank, int n_keys,
@@ -331,18 +473,22 @@ float ord2f(unsigned u)
 // Returns LIO_OK, or 1 when PCL would pass the cloud through (voxel index overflow).
 // `ws`: the temporaries; `wait`: block until the result is complete (required when ws is made of pool temporaries, which
 // are recycled when the caller returns); `box` (optional) receives min[3], max[3] of the INPUT cloud, a box around the output.
+// have_box: ws.bbox already holds the bounding box of d_in (k_transform_clouds_bbox), no pass for it.
 template <class B>
-int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out, hipStream_t s, LioVoxWs<B>& ws, bool wait, float* box)
+int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out, hipStream_t s, LioVoxWs<B>& ws, bool wait, float* box,
+                      bool have_box = false)
 {
     *n_out = 0;
     if (box) for (int a = 0; a < 6; ++a) box[a] = 0.0f;
     if (n == 0) return LIO_OK;
     B& bbox = ws.bbox;
-    HIPCHK(bbox.alloc(6 * sizeof(unsigned)));
-    const unsigned init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
-    HIPCHK(hipMemcpyAsync(bbox.p, init, sizeof(init), hipMemcpyHostToDevice, s));
-    int nbb = (n + 1023) / 1024; if (nbb > 512) nbb = 512; if (nbb < 1) nbb = 1;
-    hipLaunchKernelGGL(k_vox_bbox, dim3(nbb), dim3(256), 0, s, d_in, n, bbox.template as<unsigned>());
+    if (!have_box) {
+        HIPCHK(bbox.alloc(6 * sizeof(unsigned)));
+        const unsigned init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+        HIPCHK(hipMemcpyAsync(bbox.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+        int nbb = (n + 1023) / 1024; if (nbb > 512) nbb = 512; if (nbb < 1) nbb = 1;
+        hipLaunchKernelGGL(k_vox_bbox, dim3(nbb), dim3(256), 0, s, d_in, n, bbox.template as<unsigned>());
+    }
     unsigned hb[6];
     HIPCHK(hipMemcpyAsync(hb, bbox.p, sizeof(hb), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -373,17 +519,21 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out,
     HIPCHK(count.alloc(sizeof(int) * (size_t)g.n_keys));
     HIPCHK(start.alloc(sizeof(int) * ((size_t)g.n_keys + 1)));
     HIPCHK(rank.alloc(sizeof(int) * ((size_t)g.n_keys + 1)));
-    HIPCHK(tiles.alloc(sizeof(int) * ((size_t)lio_scan_tiles(g.n_keys) + 1)));
+    const int n_tiles = (g.n_keys + LIO_VS_TILE - 1) / LIO_VS_TILE;
+    HIPCHK(tiles.alloc(sizeof(unsigned long long) * ((size_t)n_tiles + 1)));
     const int nb = (n + 255) / 256, nk = (g.n_keys + 255) / 256;
     HIPCHK(hipMemsetAsync(count.p, 0, sizeof(int) * (size_t)g.n_keys, s));
     hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, g, d_in, n, key_of.template as<int>(), count.template as<int>());
-    lio_launch_exclusive_scan(count.template as<int>(), g.n_keys, tiles.template as<int>(), start.template as<int>(), s);
-    HIPCHK(hipMemsetAsync(count.p, 0, sizeof(int) * (size_t)g.n_keys, s));
-    hipLaunchKernelGGL(k_vox_scatter, dim3(nb), dim3(256), 0, s, key_of.template as<int>(), n, start.template as<int>(), count.template as<int>(), tmp.template as<int>());
-    hipLaunchKernelGGL(k_vox_flags, dim3(nk), dim3(256), 0, s, start.template as<int>(), g.n_keys, count.template as<int>());
-    lio_launch_exclusive_scan(count.template as<int>(), g.n_keys, tiles.template as<int>(), rank.template as<int>(), s);
+    // start (first point of every voxel) and rank (output slot of every occupied voxel) in one pass over the counts
+    hipLaunchKernelGGL(k_vox_scan_tiles, dim3(n_tiles), dim3(256), 0, s, count.template as<int>(), g.n_keys, tiles.template as<unsigned long long>());
+    hipLaunchKernelGGL(k_vox_scan_offsets, dim3(1), dim3(256), 0, s, tiles.template as<unsigned long long>(), n_tiles);
+    hipLaunchKernelGGL(k_vox_scan_apply, dim3(n_tiles), dim3(256), 0, s, count.template as<int>(), g.n_keys, tiles.template as<unsigned long long>(),
+                       start.template as<int>(), rank.template as<int>());
     int no = 0;
     HIPCHK(hipMemcpyAsync(&no, rank.template as<int>() + g.n_keys, sizeof(int), hipMemcpyDeviceToHost, s));
+    // (the scatter does not need the count: it runs while the host waits for it)
+    HIPCHK(hipMemsetAsync(count.p, 0, sizeof(int) * (size_t)g.n_keys, s));   // reused as the fill cursor
+    hipLaunchKernelGGL(k_vox_scatter, dim3(nb), dim3(256), 0, s, key_of.template as<int>(), n, start.template as<int>(), count.template as<int>(), tmp.template as<int>());
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(list.alloc(sizeof(int) * (size_t)(no ? no : 1)));
     HIPCHK(out.alloc(sizeof(float4) * (size_t)(no ? no : 1)));
@@ -470,7 +620,7 @@ struct lio_kf_store {
     std::vector<size_t> off, cnt;
     // workspace of lio_assemble_map_resident when the map is installed in a handle (kept between calls)
     LioVoxWs<LioKeep> vws;
-    LioKeep world, ds, d_kf, d_poses, d_chunks;
+    LioKeep world, ds, d_kf, d_poses, d_chunks, blk_box;
     std::vector<LioKfDesc> v_kf;
     std::vector<int2> v_chunks;
 };
@@ -493,7 +643,7 @@ extern "C" void lio_kf_store_destroy(lio_kf_store* s)
     (void)hipDeviceSynchronize();
     if (s->d_pts) (void)hipFree(s->d_pts);
     LioKeep* keep[] = { &s->vws.bbox, &s->vws.key_of, &s->vws.count, &s->vws.start, &s->vws.rank, &s->vws.tiles, &s->vws.tmp, &s->vws.list,
-                        &s->vws.large, &s->world, &s->ds, &s->d_kf, &s->d_poses, &s->d_chunks };
+                        &s->vws.large, &s->world, &s->ds, &s->d_kf, &s->d_poses, &s->d_chunks, &s->blk_box };
     for (LioKeep* k : keep) k->release();
     delete s;
 }
@@ -636,14 +786,17 @@ extern "C" int lio_assemble_map_resident(lio_s2m_handle* h, lio_kf_store* st, in
             HIPCHK(hipMemcpyAsync(st->d_poses.p, poses, sizeof(float) * 6 * (size_t)n_sel, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_kf_transforms, dim3((n_sel + 63) / 64), dim3(64), 0, s, st->d_kf.as<LioKfDesc>(), st->d_poses.as<float>(), n_sel);
         }
+        HIPCHK(st->vws.bbox.alloc(6 * sizeof(unsigned)));
+        HIPCHK(st->blk_box.alloc(sizeof(float) * 6 * (st->v_chunks.size() ? st->v_chunks.size() : 1)));
         if (!st->v_chunks.empty()) {
             HIPCHK(hipMemcpyAsync(st->d_chunks.p, st->v_chunks.data(), sizeof(int2) * st->v_chunks.size(), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_transform_clouds, dim3((unsigned)st->v_chunks.size()), dim3(256), 0, s, st->d_pts,
-                               st->d_kf.as<LioKfDesc>(), st->d_chunks.as<int2>(), st->world.as<float4>());
+            hipLaunchKernelGGL(k_transform_clouds_bbox, dim3((unsigned)st->v_chunks.size()), dim3(256), 0, s, st->d_pts,
+                               st->d_kf.as<LioKfDesc>(), st->d_chunks.as<int2>(), st->world.as<float4>(), st->blk_box.as<float>());
         }
+        hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, s, st->blk_box.as<float>(), (int)st->v_chunks.size(), st->vws.bbox.as<unsigned>());
         int no = 0;
         float box[6];
-        rc = voxel_grid_device<LioKeep>(st->world.as<float4>(), (int)total, leaf, st->ds, &no, s, st->vws, false, box);
+        rc = voxel_grid_device<LioKeep>(st->world.as<float4>(), (int)total, leaf, st->ds, &no, s, st->vws, false, box, true);
         if (rc < 0) return rc;
         // (`poses` was consumed by the voxel filter's first wait, which follows its copy on the same stream)
         const int rc3 = lio_s2m_set_map_device_bbox(h, st->ds.as<float4>(), (size_t)no, box);

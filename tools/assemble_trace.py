@@ -19,4 +19,5 @@ t0 = time.perf_counter()
 n = 20
 for _ in range(n):
     _, n_out, _ = store.assemble(ids, kp, 0.5, s2m=node, want_output=False)
-print(f"assemble: {1e3 * (time.perf_counter() - t0) / n:.3f} ms per call, {sum(len(c) for c in kc)} points in, {n_out} out")
+node.profile()                       # (waits for the last build, which is still in flight when assemble returns)
+print(f"assemble: {1e3 * (time.perf_counter() - t0) / n:.3f} ms per call incl. the grid build, {sum(len(c) for c in kc)} points in, {n_out} out")
