@@ -479,11 +479,11 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
         cell *= 1.5f;   // larger cells keep the search exact, only less selective
     }
     h->grid = g;
-    HIPCHK(lio_grow(&h->d_cell_count, &h->cap_cell_count, (size_t)g.n_cells));
+    HIPCHK(lio_grow(&h->d_cell_count, &h->cap_cell_count, 2 * (size_t)g.n_cells));       // (point counts + neighbourhood-row lengths)
     HIPCHK(lio_grow(&h->d_cell_start, &h->cap_cell_start, (size_t)g.n_cells + 1));
     HIPCHK(lio_grow(&h->d_nbr_start, &h->cap_nbr_start, (size_t)g.n_cells + 1));
     HIPCHK(lio_grow(&h->d_nbr_pts, &h->cap_nbr_pts, nn * (size_t)((2 * g.k + 1) * (2 * g.k + 1)) + LIO_ROW_ALIGN * (size_t)g.ny * g.nz + 4 * LIO_ROW_ALIGN, 1.05));
-    HIPCHK(lio_grow(&h->d_tile_sums, &h->cap_tile_sums, (size_t)lio_scan_tiles(g.n_cells) + 1));
+    HIPCHK(lio_grow(&h->d_tile_sums, &h->cap_tile_sums, 2 * ((size_t)lio_scan_tiles(g.n_cells) + 1)));   // (64-bit pair sums)
 
     HIPCHK(hipEventRecord(box ? h->ev_mapl[0] : h->ev_map[0], h->stream));
     if (n) {
