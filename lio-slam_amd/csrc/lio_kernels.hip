@@ -14,6 +14,7 @@
 #include "lio_kernels.h"
 
 #include "lio_s2m_device.h"
+#include "lio_scan2.h"
 
 LIO_DEV unsigned lio_f2ord(float f)   // order-preserving float -> uint
 {
@@ -172,78 +173,6 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int* __restrict__ in, 
         if (base + k < n) out[base + k] = run;
         run += v[k];
         if (base + k == n - 1) out[n] = run;
-    }
-}
-
-// Two exclusive scans over the same index range in one pass (the per-cell point counts and the per-cell neighbourhood-row
-// lengths of the map build): both running sums travel in one 64-bit word (each < 2^31).
-LIO_DEV unsigned long long lio_block_exclusive_scan64(unsigned long long v, unsigned long long* total, unsigned long long* s_wave)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    unsigned long long wave_off = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { const unsigned long long q = s_wave[w]; if (w < wave) wave_off += q; tot += q; }
-    __syncthreads();
-    *total = tot;
-    return wave_off + incl - v;
-}
-
-__global__ __launch_bounds__(256) void k_scan2_tile_sums(const int* __restrict__ a, const int* __restrict__ b, int n,
-                                                         unsigned long long* __restrict__ tile_sums)
-{
-    __shared__ unsigned long long s_wave[4];
-    const int base = blockIdx.x * LIO_SCAN_TILE + threadIdx.x * LIO_SCAN_ITEMS;
-    unsigned long long acc = 0;
-#pragma unroll
-    for (int k = 0; k < LIO_SCAN_ITEMS; ++k)
-        if (base + k < n) acc += (unsigned long long)(unsigned)a[base + k] + ((unsigned long long)(unsigned)b[base + k] << 32);
-    unsigned long long tot;
-    lio_block_exclusive_scan64(acc, &tot, s_wave);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(256) void k_scan2_tile_offsets(unsigned long long* __restrict__ tile_sums, int n_tiles)
-{
-    __shared__ unsigned long long s_wave[4];
-    unsigned long long carry = 0;
-    for (int t = 0; t < n_tiles; t += 256) {
-        const int i = t + threadIdx.x;
-        const unsigned long long v = i < n_tiles ? tile_sums[i] : 0ull;
-        unsigned long long tot;
-        const unsigned long long ex = lio_block_exclusive_scan64(v, &tot, s_wave);
-        if (i < n_tiles) tile_sums[i] = carry + ex;
-        carry += tot;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_scan2_apply(const int* __restrict__ a, const int* __restrict__ b, int n,
-                                                     const unsigned long long* __restrict__ tile_offsets,
-                                                     int* __restrict__ out_a /* n+1 */, int* __restrict__ out_b /* n+1 */)
-{
-    __shared__ unsigned long long s_wave[4];
-    const int base = blockIdx.x * LIO_SCAN_TILE + threadIdx.x * LIO_SCAN_ITEMS;
-    unsigned long long v[LIO_SCAN_ITEMS];
-    unsigned long long acc = 0;
-#pragma unroll
-    for (int k = 0; k < LIO_SCAN_ITEMS; ++k) {
-        v[k] = (base + k < n) ? (unsigned long long)(unsigned)a[base + k] + ((unsigned long long)(unsigned)b[base + k] << 32) : 0ull;
-        acc += v[k];
-    }
-    unsigned long long tot;
-    unsigned long long run = tile_offsets[blockIdx.x] + lio_block_exclusive_scan64(acc, &tot, s_wave);
-#pragma unroll
-    for (int k = 0; k < LIO_SCAN_ITEMS; ++k) {
-        if (base + k < n) { out_a[base + k] = (int)(unsigned)run; out_b[base + k] = (int)(run >> 32); }
-        run += v[k];
-        if (base + k == n - 1) { out_a[n] = (int)(unsigned)run; out_b[n] = (int)(run >> 32); }
     }
 }
 
@@ -1201,16 +1130,13 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
     const int nb = (n + 255) / 256;
     int* nbr_count = cell_count + g.n_cells;
     unsigned long long* tiles64 = reinterpret_cast<unsigned long long*>(tile_sums);
-    const int n_tiles = (g.n_cells + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE;
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * 2 * (size_t)g.n_cells, s);
     hipLaunchKernelGGL(k_map_cell_count, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, cell_count);
     hipLaunchKernelGGL(k_map_nbr_count, dim3(nb), dim3(256), 0, s, g, cell_of, n, nbr_count);
     hipLaunchKernelGGL(k_map_nbr_pad_rows, dim3((g.ny * g.nz + 3) / 4), dim3(256), 0, s, g, nbr_count);
     // cell_start (cell-sorted copy, 1x: the LDS-staged variant) and nbr_start (replicated neighbourhood rows: the default
     // candidate scan) in one scan pass
-    hipLaunchKernelGGL(k_scan2_tile_sums, dim3(n_tiles), dim3(256), 0, s, cell_count, nbr_count, g.n_cells, tiles64);
-    hipLaunchKernelGGL(k_scan2_tile_offsets, dim3(1), dim3(256), 0, s, tiles64, n_tiles);
-    hipLaunchKernelGGL(k_scan2_apply, dim3(n_tiles), dim3(256), 0, s, cell_count, nbr_count, g.n_cells, tiles64, cell_start, nbr_start);
+    lio_launch_scan2<false>(cell_count, nbr_count, g.n_cells, tiles64, cell_start, nbr_start, s);
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * 2 * (size_t)g.n_cells, s);   // reused as the fill cursors
     hipLaunchKernelGGL(k_map_scatter, dim3(nb), dim3(256), 0, s, x, y, z, n, cell_of, cell_start, cell_count, sorted);
     {

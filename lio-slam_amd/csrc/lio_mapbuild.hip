@@ -13,6 +13,7 @@
 #include "lio_kernels.h"
 #include "lio_pool.h"
 #include "lio_device_math.h"
+#include "lio_scan2.h"
 
 int lio_fail_ext(int code, const char* what, hipError_t e);                    // liogpu_api.hip
 int lio_s2m_set_map_device_xyzi(lio_s2m_handle* h, const float4* d_xyzi, size_t n);   // liogpu_api.hip
@@ -207,78 +208,6 @@ __global__ void k_vox_flags(const int* __restrict__ start, int n_keys, int* __re
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_keys) flag[k] = (start[k + 1] > start[k]) ? 1 : 0;
-}
-
-// Two exclusive scans of the per-voxel counts in one pass: start[k] = points in voxels < k, rank[k] = OCCUPIED voxels < k
-// (the output slot of voxel k).  Both sums travel in one 64-bit word (low: points < 2^31, high: voxels < 2^29).
-#define LIO_VS_ITEMS 16
-#define LIO_VS_TILE (256 * LIO_VS_ITEMS)
-__device__ __forceinline__ unsigned long long vox_block_exscan(unsigned long long v, unsigned long long* total, unsigned long long* s_wave)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    unsigned long long wave_off = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { const unsigned long long q = s_wave[w]; if (w < wave) wave_off += q; tot += q; }
-    __syncthreads();
-    *total = tot;
-    return wave_off + incl - v;
-}
-
-__global__ __launch_bounds__(256) void k_vox_scan_tiles(const int* __restrict__ count, int n, unsigned long long* __restrict__ tile_sums)
-{
-    __shared__ unsigned long long s_wave[4];
-    const int base = blockIdx.x * LIO_VS_TILE + threadIdx.x * LIO_VS_ITEMS;
-    unsigned long long acc = 0;
-#pragma unroll
-    for (int k = 0; k < LIO_VS_ITEMS; ++k)
-        if (base + k < n) { const int c = count[base + k]; acc += (unsigned long long)(unsigned)c + (c > 0 ? (1ull << 32) : 0ull); }
-    unsigned long long tot;
-    vox_block_exscan(acc, &tot, s_wave);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(256) void k_vox_scan_offsets(unsigned long long* __restrict__ tile_sums, int n_tiles)
-{
-    __shared__ unsigned long long s_wave[4];
-    unsigned long long carry = 0;
-    for (int b = 0; b < n_tiles; b += 256) {
-        const int i = b + threadIdx.x;
-        const unsigned long long v = i < n_tiles ? tile_sums[i] : 0ull;
-        unsigned long long tot;
-        const unsigned long long ex = vox_block_exscan(v, &tot, s_wave);
-        if (i < n_tiles) tile_sums[i] = carry + ex;
-        carry += tot;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_vox_scan_apply(const int* __restrict__ count, int n, const unsigned long long* __restrict__ tile_offsets,
-                                                        int* __restrict__ start /* n+1 */, int* __restrict__ rank /* n+1 */)
-{
-    __shared__ unsigned long long s_wave[4];
-    const int base = blockIdx.x * LIO_VS_TILE + threadIdx.x * LIO_VS_ITEMS;
-    int v[LIO_VS_ITEMS];
-    unsigned long long acc = 0;
-#pragma unroll
-    for (int k = 0; k < LIO_VS_ITEMS; ++k) {
-        v[k] = (base + k < n) ? count[base + k] : 0;
-        acc += (unsigned long long)(unsigned)v[k] + (v[k] > 0 ? (1ull << 32) : 0ull);
-    }
-    unsigned long long tot;
-    unsigned long long run = tile_offsets[blockIdx.x] + vox_block_exscan(acc, &tot, s_wave);
-#pragma unroll
-    for (int k = 0; k < LIO_VS_ITEMS; ++k) {
-        if (base + k < n) { start[base + k] = (int)(unsigned)run; rank[base + k] = (int)(run >> 32); }
-        run += (unsigned long long)(unsigned)v[k] + (v[k] > 0 ? (1ull << 32) : 0ull);
-        if (base + k == n - 1) { start[n] = (int)(unsigned)run; rank[n] = (int)(run >> 32); }
-    }
 }
 
 __global__ void k_vox_list(const int* __restrict__ start, const int* __restrict__ rank, int n_keys,
@@ -519,16 +448,14 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out,
     HIPCHK(count.alloc(sizeof(int) * (size_t)g.n_keys));
     HIPCHK(start.alloc(sizeof(int) * ((size_t)g.n_keys + 1)));
     HIPCHK(rank.alloc(sizeof(int) * ((size_t)g.n_keys + 1)));
-    const int n_tiles = (g.n_keys + LIO_VS_TILE - 1) / LIO_VS_TILE;
+    const int n_tiles = (g.n_keys + LIO_S2_TILE - 1) / LIO_S2_TILE;
     HIPCHK(tiles.alloc(sizeof(unsigned long long) * ((size_t)n_tiles + 1)));
     const int nb = (n + 255) / 256, nk = (g.n_keys + 255) / 256;
     HIPCHK(hipMemsetAsync(count.p, 0, sizeof(int) * (size_t)g.n_keys, s));
     hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, g, d_in, n, key_of.template as<int>(), count.template as<int>());
     // start (first point of every voxel) and rank (output slot of every occupied voxel) in one pass over the counts
-    hipLaunchKernelGGL(k_vox_scan_tiles, dim3(n_tiles), dim3(256), 0, s, count.template as<int>(), g.n_keys, tiles.template as<unsigned long long>());
-    hipLaunchKernelGGL(k_vox_scan_offsets, dim3(1), dim3(256), 0, s, tiles.template as<unsigned long long>(), n_tiles);
-    hipLaunchKernelGGL(k_vox_scan_apply, dim3(n_tiles), dim3(256), 0, s, count.template as<int>(), g.n_keys, tiles.template as<unsigned long long>(),
-                       start.template as<int>(), rank.template as<int>());
+    lio_launch_scan2<true>(count.template as<int>(), nullptr, g.n_keys, tiles.template as<unsigned long long>(),
+                           start.template as<int>(), rank.template as<int>(), s);
     int no = 0;
     HIPCHK(hipMemcpyAsync(&no, rank.template as<int>() + g.n_keys, sizeof(int), hipMemcpyDeviceToHost, s));
     // (the scatter does not need the count: it runs while the host waits for it)
