@@ -662,12 +662,18 @@ __global__ __launch_bounds__(256) void k_shard_cull(LioIterParams P, LioShardPla
         }
         if (!whole && (c_hi < P.shard.lo || c_lo >= P.shard.hi)) mode = 1;
     }
-    if (c == 0) skip[i] = (unsigned char)mode;
-    if (mode != 1) return;
-    if (P.d5_cache) {                                       // the search bound of a point is only valid from one pass to the very next
+    // The search bound of a point is only valid from one pass to the very next.  A workgroup that sat the LAST pass out
+    // and takes part in this one drops its points' bounds here (its previous decision is still in skip[i]; pass 0 never
+    // reads a bound and the host clears them before it).  Dropping them on every skipped workgroup instead cost 24 M
+    // scattered stores per launch on an 8-way partition.
+    const int prev_mode = skip[i];
+    if (P.d5_cache && mode != 1 && prev_mode == 1 && st->iter > 0) {
         for (int j = c; j < LIO_BLOCK; j += 8)
             if (bd.first + j < st->n_pts) P.d5_cache[base + bd.first + j] = -1.0f;
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // (all eight lanes have read skip[i] before lane 0 rewrites it)
+    if (c == 0) skip[i] = (unsigned char)mode;
+    if (mode != 1) return;
     double* part0 = P.partials + ((size_t)bd.scan * P.max_blk + bd.blk) * LIO_SUMS;
     for (int j = c; j < 28; j += 8) __hip_atomic_store(part0 + j, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (every lane of the wave has drained its stores before any lane arrives)
