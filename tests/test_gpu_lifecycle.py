@@ -97,3 +97,31 @@ def test_error_then_reuse(pkg, small_case):
     np.testing.assert_array_equal(p, pw)
     assert r.iters == rw.iters
     s.close(); ref.close()
+
+
+def test_sharer_follows_an_asynchronously_installed_map(pkg, small_case):
+    """lio_assemble_map_resident returns with the owner's grid build still in flight on the owner's stream; a handle
+    sharing that map runs on its own stream and must wait for the build (event), not read a half-built grid."""
+    qs = small_case["queries"]
+    m = small_case["map"]
+    rec = np.zeros((len(m), 4), np.float32)
+    rec[:, :3] = m
+    st = pkg.KeyframeStore()
+    ids = [st.add(rec[k::5]) for k in range(5)]
+    ident = np.zeros((5, 6), np.float32)
+    owner = pkg.ScanToMap()
+    sharer = pkg.ScanToMap()
+    sharer.share_map(owner)
+    ref = pkg.ScanToMap()
+    for rep in range(6):
+        leaf = 0.4 + 0.05 * (rep % 3)                       # a different map every time
+        out, n_out, _ = st.assemble(ids, ident, leaf, s2m=None, want_output=True, max_out=len(m))
+        st.assemble(ids, ident, leaf, s2m=owner, want_output=False)          # asynchronous installation
+        p_sh, r_sh, _ = sharer.scan2MapOptimization(qs[rep % len(qs)]["scan"], qs[rep % len(qs)]["pose_init"])
+        ref.set_map(np.ascontiguousarray(out[:n_out, :3]))
+        p_ref, r_ref, _ = ref.scan2MapOptimization(qs[rep % len(qs)]["scan"], qs[rep % len(qs)]["pose_init"])
+        np.testing.assert_array_equal(p_sh, p_ref)
+        assert r_sh.iters == r_ref.iters and list(r_sh.n_corr_iter) == list(r_ref.n_corr_iter)
+    for h in (sharer, owner, ref):
+        h.close()
+    st.close()
