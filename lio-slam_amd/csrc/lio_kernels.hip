@@ -200,19 +200,24 @@ __global__ void k_map_scatter(const float* __restrict__ x, const float* __restri
 // divergent runs.  Costs (2k+1)^2 x 16 B of HBM per map point (k=2: 400 MB per
 // million points; sized for 288 GB).  Finer cells (k=2) cut the searched
 // volume from 27 to 15.6 m^3 around a 1 m gate, i.e. ~1.7x fewer candidates.
-__global__ void k_map_nbr_count(LioGrid g, const int* __restrict__ cell_of, int n, int* __restrict__ nbr_count)
+// One thread per (map point, neighbouring (y,z) row): the point joins the row lists of the (2k+1)^2 rows around its own,
+// at its own x cell.  slot[t] = its arrival number in that cell's list (the value the counting atomic returns; -1: no such
+// row), so that k_map_nbr_scatter needs no second round of atomics.  The order inside a list is arbitrary: the candidate
+// scan keeps the five smallest (d2, index) keys whatever order they come in.
+__global__ void k_map_nbr_count(LioGrid g, const int* __restrict__ cell_of, int n, int* __restrict__ nbr_count, int* __restrict__ slot)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int side = 2 * g.k + 1, reps = side * side;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n * reps) return;
+    const int i = (int)(t / reps), r = (int)(t - (long long)i * reps);
     const int c = cell_of[i];
-    if (c < 0) return;
-    const int x = c % g.nx, yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
-    for (int dz = -g.k; dz <= g.k; ++dz)
-        for (int dy = -g.k; dy <= g.k; ++dy) {
-            const int yy = y + dy, zz = z + dz;
-            if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz)
-                atomicAdd(&nbr_count[(zz * g.ny + yy) * g.nx + x], 1);
-        }
+    int sl = -1;
+    if (c >= 0) {
+        const int x = c % g.nx, yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
+        const int yy = y + r % side - g.k, zz = z + r / side - g.k;
+        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) sl = atomicAdd(&nbr_count[(zz * g.ny + yy) * g.nx + x], 1);
+    }
+    slot[t] = sl;
 }
 
 // Record layout of nbr_pts: records are stored in PAIRS, transposed, so that one 16-byte load
@@ -252,24 +257,19 @@ __global__ void k_map_nbr_fill(float4* __restrict__ nbr_pts, int n_rec4)
 
 __global__ void k_map_nbr_scatter(LioGrid g, const float* __restrict__ x_, const float* __restrict__ y_,
                                   const float* __restrict__ z_, int n, const int* __restrict__ cell_of,
-                                  const int* __restrict__ nbr_start, int* __restrict__ nbr_fill,
+                                  const int* __restrict__ nbr_start, const int* __restrict__ slot,
                                   float4* __restrict__ nbr_pts)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int side = 2 * g.k + 1, reps = side * side;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n * reps) return;
+    const int sl = slot[t];
+    if (sl < 0) return;
+    const int i = (int)(t / reps), r = (int)(t - (long long)i * reps);
     const int c = cell_of[i];
-    if (c < 0) return;
-    const float px = x_[i], py = y_[i], pz = z_[i], pw = __int_as_float(i);
     const int x = c % g.nx, yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
-    for (int dz = -g.k; dz <= g.k; ++dz)
-        for (int dy = -g.k; dy <= g.k; ++dy) {
-            const int yy = y + dy, zz = z + dz;
-            if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-                const int key = (zz * g.ny + yy) * g.nx + x;
-                lio_nbr_store(reinterpret_cast<float*>(nbr_pts), nbr_start[key] + atomicAdd(&nbr_fill[key], 1),
-                              px, py, pz, pw);
-            }
-        }
+    const int yy = y + r % side - g.k, zz = z + r / side - g.k;
+    lio_nbr_store(reinterpret_cast<float*>(nbr_pts), nbr_start[(zz * g.ny + yy) * g.nx + x] + sl, x_[i], y_[i], z_[i], __int_as_float(i));
 }
 
 // ------------------------------------------------- scan tile sort (upload)
@@ -1129,27 +1129,30 @@ void lio_launch_exclusive_scan(const int* in, int n, int* tile_sums, int* out, h
 
 // cell_count: 2 x n_cells ints (point counts, then neighbourhood-row lengths; both reused as fill cursors);
 // tile_sums: 2 x (lio_scan_tiles(n_cells) + 1) ints, 8-byte aligned (one 64-bit pair sum per tile)
+// nbr_slot: n x (2k+1)^2 ints
 void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, const float* z, int n,
                           int* cell_of, int* cell_count, int* cell_start, int* tile_sums,
-                          float4* sorted, int* nbr_start, float4* nbr_pts, hipStream_t s)
+                          float4* sorted, int* nbr_start, float4* nbr_pts, int* nbr_slot, hipStream_t s)
 {
     const int nb = (n + 255) / 256;
+    const long long n_rep = (long long)n * (2 * g.k + 1) * (2 * g.k + 1);
+    const unsigned nbr = (unsigned)((n_rep + 255) / 256);
     int* nbr_count = cell_count + g.n_cells;
     unsigned long long* tiles64 = reinterpret_cast<unsigned long long*>(tile_sums);
     (void)hipMemsetAsync(cell_count, 0, sizeof(int) * 2 * (size_t)g.n_cells, s);
     hipLaunchKernelGGL(k_map_cell_count, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, cell_count);
-    hipLaunchKernelGGL(k_map_nbr_count, dim3(nb), dim3(256), 0, s, g, cell_of, n, nbr_count);
+    hipLaunchKernelGGL(k_map_nbr_count, dim3(nbr), dim3(256), 0, s, g, cell_of, n, nbr_count, nbr_slot);
     hipLaunchKernelGGL(k_map_nbr_pad_rows, dim3((g.ny * g.nz + 3) / 4), dim3(256), 0, s, g, nbr_count);
     // cell_start (cell-sorted copy, 1x: the LDS-staged variant) and nbr_start (replicated neighbourhood rows: the default
     // candidate scan) in one scan pass
     lio_launch_scan2<false>(cell_count, nbr_count, g.n_cells, tiles64, cell_start, nbr_start, s);
-    (void)hipMemsetAsync(cell_count, 0, sizeof(int) * 2 * (size_t)g.n_cells, s);   // reused as the fill cursors
+    (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);       // reused as the fill cursor of the cell-sorted copy
     hipLaunchKernelGGL(k_map_scatter, dim3(nb), dim3(256), 0, s, x, y, z, n, cell_of, cell_start, cell_count, sorted);
     {
         const int n_rec4 = n * (2 * g.k + 1) * (2 * g.k + 1) + LIO_ROW_ALIGN * g.ny * g.nz + 2 * LIO_ROW_ALIGN;   // + row and tail padding
         hipLaunchKernelGGL(k_map_nbr_fill, dim3((n_rec4 + 255) / 256), dim3(256), 0, s, nbr_pts, n_rec4);
     }
-    hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, nbr_start, nbr_count, nbr_pts);
+    hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nbr), dim3(256), 0, s, g, x, y, z, n, cell_of, nbr_start, nbr_slot, nbr_pts);
 }
 
 int lio_scan_tiles(int n_cells) { return (n_cells + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE; }

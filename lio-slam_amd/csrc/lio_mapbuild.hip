@@ -181,8 +181,11 @@ __global__ __launch_bounds__(256) void k_bbox_reduce(const float* __restrict__ b
 struct LioVoxGrid { float inv; int min_b0, min_b1, min_b2, mul1, mul2, n_keys; };
 
 // voxel index of pcl::VoxelGrid: x-fastest over the cloud's own bounding box
+// key_of[i] = voxel of point i, slot_of[i] = its arrival number inside the voxel (the value the counting atomic returns):
+// with the exclusive scan of the counts that is the point's place in the voxel-sorted index list, so the scatter needs no
+// second round of atomics (the order inside a voxel is arbitrary here; the centroid kernels sort by input index).
 __global__ void k_vox_keys(LioVoxGrid g, const float4* __restrict__ p, int n, int* __restrict__ key_of,
-                           int* __restrict__ count)
+                           int* __restrict__ slot_of, int* __restrict__ count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -192,22 +195,15 @@ __global__ void k_vox_keys(LioVoxGrid g, const float4* __restrict__ p, int n, in
     const int i2 = (int)(floorf(v.z * g.inv) - (float)g.min_b2);
     const int key = i0 + i1 * g.mul1 + i2 * g.mul2;
     key_of[i] = key;
-    atomicAdd(&count[key], 1);
+    slot_of[i] = atomicAdd(&count[key], 1);
 }
 
-__global__ void k_vox_scatter(const int* __restrict__ key_of, int n, const int* __restrict__ start,
-                              int* __restrict__ fill, int* __restrict__ tmp)
+__global__ void k_vox_scatter(const int* __restrict__ key_of, const int* __restrict__ slot_of, int n, const int* __restrict__ start,
+                              int* __restrict__ tmp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int k = key_of[i];
-    tmp[start[k] + atomicAdd(&fill[k], 1)] = i;
-}
-
-__global__ void k_vox_flags(const int* __restrict__ start, int n_keys, int* __restrict__ flag)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_keys) flag[k] = (start[k + 1] > start[k]) ? 1 : 0;
+    tmp[start[key_of[i]] + slot_of[i]] = i;
 }
 
 __global__ void k_vox_list(const int* __restrict__ start, const int* __restrict__ rank, int n_keys,
@@ -388,7 +384,7 @@ struct LioKeep {
 namespace {
 typedef LioTemp Buf;         // temporaries come from the recycling pool (lio_pool.h)
 
-template <class B> struct LioVoxWs { B bbox, key_of, count, start, rank, tiles, tmp, list, large; };
+template <class B> struct LioVoxWs { B bbox, key_of, slot_of, count, start, rank, tiles, tmp, list, large; };
 
 float ord2f(unsigned u)
 {
@@ -442,8 +438,9 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out,
     const long long n_keys_ll = (long long)d0 * d1 * d2;
     if (n_keys_ll > (1LL << 29)) return lio_fail_ext(LIO_ERR_CAPACITY, "voxel grid has more than 2^29 voxels", hipSuccess);
     g.n_keys = (int)n_keys_ll;
-    B &key_of = ws.key_of, &count = ws.count, &start = ws.start, &rank = ws.rank, &tiles = ws.tiles, &tmp = ws.tmp, &list = ws.list;
+    B &key_of = ws.key_of, &slot_of = ws.slot_of, &count = ws.count, &start = ws.start, &rank = ws.rank, &tiles = ws.tiles, &tmp = ws.tmp, &list = ws.list;
     HIPCHK(key_of.alloc(sizeof(int) * (size_t)n));
+    HIPCHK(slot_of.alloc(sizeof(int) * (size_t)n));
     HIPCHK(tmp.alloc(sizeof(int) * (size_t)n));
     HIPCHK(count.alloc(sizeof(int) * (size_t)g.n_keys));
     HIPCHK(start.alloc(sizeof(int) * ((size_t)g.n_keys + 1)));
@@ -452,15 +449,14 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out,
     HIPCHK(tiles.alloc(sizeof(unsigned long long) * ((size_t)n_tiles + 1)));
     const int nb = (n + 255) / 256, nk = (g.n_keys + 255) / 256;
     HIPCHK(hipMemsetAsync(count.p, 0, sizeof(int) * (size_t)g.n_keys, s));
-    hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, g, d_in, n, key_of.template as<int>(), count.template as<int>());
+    hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, g, d_in, n, key_of.template as<int>(), slot_of.template as<int>(), count.template as<int>());
     // start (first point of every voxel) and rank (output slot of every occupied voxel) in one pass over the counts
     lio_launch_scan2<true>(count.template as<int>(), nullptr, g.n_keys, tiles.template as<unsigned long long>(),
                            start.template as<int>(), rank.template as<int>(), s);
     int no = 0;
     HIPCHK(hipMemcpyAsync(&no, rank.template as<int>() + g.n_keys, sizeof(int), hipMemcpyDeviceToHost, s));
     // (the scatter does not need the count: it runs while the host waits for it)
-    HIPCHK(hipMemsetAsync(count.p, 0, sizeof(int) * (size_t)g.n_keys, s));   // reused as the fill cursor
-    hipLaunchKernelGGL(k_vox_scatter, dim3(nb), dim3(256), 0, s, key_of.template as<int>(), n, start.template as<int>(), count.template as<int>(), tmp.template as<int>());
+    hipLaunchKernelGGL(k_vox_scatter, dim3(nb), dim3(256), 0, s, key_of.template as<int>(), slot_of.template as<int>(), n, start.template as<int>(), tmp.template as<int>());
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(list.alloc(sizeof(int) * (size_t)(no ? no : 1)));
     HIPCHK(out.alloc(sizeof(float4) * (size_t)(no ? no : 1)));
@@ -569,7 +565,7 @@ extern "C" void lio_kf_store_destroy(lio_kf_store* s)
     (void)hipSetDevice(s->device_id);
     (void)hipDeviceSynchronize();
     if (s->d_pts) (void)hipFree(s->d_pts);
-    LioKeep* keep[] = { &s->vws.bbox, &s->vws.key_of, &s->vws.count, &s->vws.start, &s->vws.rank, &s->vws.tiles, &s->vws.tmp, &s->vws.list,
+    LioKeep* keep[] = { &s->vws.bbox, &s->vws.key_of, &s->vws.slot_of, &s->vws.count, &s->vws.start, &s->vws.rank, &s->vws.tiles, &s->vws.tmp, &s->vws.list,
                         &s->vws.large, &s->world, &s->ds, &s->d_kf, &s->d_poses, &s->d_chunks, &s->blk_box };
     for (LioKeep* k : keep) k->release();
     delete s;

@@ -64,6 +64,7 @@ struct lio_s2m_handle {
     int* d_tile_sums = nullptr;  size_t cap_tile_sums = 0;
     int* d_nbr_start = nullptr;  size_t cap_nbr_start = 0;
     float4* d_nbr_pts = nullptr; size_t cap_nbr_pts = 0;
+    int* d_nbr_slot = nullptr;   size_t cap_nbr_slot = 0;      // [n_map][(2k+1)^2] place of every replica inside its row-cell list
     unsigned* d_bbox = nullptr;
     unsigned char* d_stage = nullptr; size_t cap_stage = 0;
     LioGrid grid{};
@@ -380,7 +381,7 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
                      h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
                      h->d_nn_cache, h->d_summary, h->d_groups, h->d_cache_idx, h->d_cache_q, h->d_pt_flag,
-                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox, h->d_block_box, h->d_blk_skip, h->d_plane, h->d_plane_state, h->d_gen, h->d_spec_sums };
+                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox, h->d_block_box, h->d_blk_skip, h->d_plane, h->d_plane_state, h->d_gen, h->d_spec_sums, h->d_nbr_slot };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < LIO_MAX_ITERS; ++i) {               // (a handle whose creation failed half-way holds nulls)
         if (h->ev_beg[i]) (void)hipEventDestroy(h->ev_beg[i]);
@@ -484,11 +485,12 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
     HIPCHK(lio_grow(&h->d_nbr_start, &h->cap_nbr_start, (size_t)g.n_cells + 1));
     HIPCHK(lio_grow(&h->d_nbr_pts, &h->cap_nbr_pts, nn * (size_t)((2 * g.k + 1) * (2 * g.k + 1)) + LIO_ROW_ALIGN * (size_t)g.ny * g.nz + 4 * LIO_ROW_ALIGN, 1.05));
     HIPCHK(lio_grow(&h->d_tile_sums, &h->cap_tile_sums, 2 * ((size_t)lio_scan_tiles(g.n_cells) + 1)));   // (64-bit pair sums)
+    HIPCHK(lio_grow(&h->d_nbr_slot, &h->cap_nbr_slot, nn * (size_t)((2 * g.k + 1) * (2 * g.k + 1)), 1.05));
 
     HIPCHK(hipEventRecord(box ? h->ev_mapl[0] : h->ev_map[0], h->stream));
     if (n) {
         lio_launch_map_build(g, h->d_mx, h->d_my, h->d_mz, (int)n, h->d_cell_of, h->d_cell_count,
-                             h->d_cell_start, h->d_tile_sums, h->d_sorted, h->d_nbr_start, h->d_nbr_pts, h->stream);
+                             h->d_cell_start, h->d_tile_sums, h->d_sorted, h->d_nbr_start, h->d_nbr_pts, h->d_nbr_slot, h->stream);
     } else {
         HIPCHK(hipMemsetAsync(h->d_cell_start, 0, sizeof(int) * ((size_t)g.n_cells + 1), h->stream));
         HIPCHK(hipMemsetAsync(h->d_nbr_start, 0, sizeof(int) * ((size_t)g.n_cells + 1), h->stream));
