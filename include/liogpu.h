@@ -94,8 +94,10 @@ typedef struct lio_s2m_config {
                                 iterations; 0.17 against 0.25 ms per registration on MI355X); 1 = always one launch per
                                 iteration; 4 = the one-launch loop for every batch of at most one workgroup per compute
                                 unit; 2 = split: neighbour certificate / candidate scan / fit as three launches; 3 = the
-                                per-iteration launch with the certificate inside (k_s2m_iterate_cert); 2 measured slower
-                                and 3 no faster, both kept as options with their evidence                               */
+                                per-iteration launch with the certificate inside (k_s2m_iterate_cert); 5 = the
+                                per-iteration launch that keeps a point's plane while its neighbour tuple stands
+                                (k_s2m_iterate_reuse); 2 and 5 measured slower and 3 no faster, all three kept as
+                                options with their evidence                                                              */
     int32_t n_devices;       /* 1 (default) = the single device `device_id`.  > 1: in-library multi-GPU -- the local
                                 map is cut into slabs (+ one-cell halo) over device_ids[0..n_devices), every
                                 registration's points are processed by the device owning their map cell and the

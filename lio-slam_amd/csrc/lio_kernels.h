@@ -65,6 +65,7 @@ void lio_launch_init_state(LioScanState* st, int n_scans, float* poses, bool fro
 void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s, bool corner = false);
 void lio_launch_split_iteration(const LioSplitParams& S, int n_blocks, hipStream_t s);
 void lio_launch_iterate_cert(const LioSplitParams& S, int n_blocks, hipStream_t s);
+void lio_launch_iterate_reuse(const LioSplitParams& S, int n_blocks, hipStream_t s);
 void lio_launch_persist(const LioIterParams& P, int n_blocks, unsigned* gen, unsigned epoch, const unsigned char* stage, size_t stride,
                         int n_scans, unsigned* spec, double* spec_sums, const float* poses0, hipStream_t s);
 void lio_launch_pack_summary(const LioScanState* st, int n_scans, float* out, hipStream_t s);

@@ -118,6 +118,7 @@ struct lio_s2m_handle {
     // split pipeline (cfg.pipeline): neighbour cache + per-iteration scan work list
     bool split = false;               // the resident batch runs k_s2m_cert / _scan / _fit instead of k_s2m_iterate
     bool certk = false;               // the resident batch runs k_s2m_iterate_cert (cfg.pipeline = 3)
+    bool reusek = false;              // the resident batch runs k_s2m_iterate_reuse (cfg.pipeline = 5: kept planes)
     // one-launch loop (cfg.pipeline = 4, k_s2m_persist): per-scan generation numbers
     unsigned* d_gen = nullptr; size_t cap_gen = 0;     // [2][cap_gen / 2]: generation numbers, then the speculation states
     double* d_spec_sums = nullptr; size_t cap_spec_sums = 0;   // sums of the first solve of every scan (roll-back of the speculation)
@@ -798,7 +799,7 @@ static bool lio_persist_eligible(const lio_s2m_handle* h)
     int limit = 0;
     if (h->cfg.pipeline == 4) limit = h->n_cu;
     else if (h->cfg.pipeline == 0 && !h->cfg.use_graph && h->cfg.profile != 2) limit = h->n_cu / 4;
-    return limit > 0 && !h->split && !h->certk && !h->cfg.use_lds && h->ppt == 1 && h->shard.axis < 0 &&
+    return limit > 0 && !h->split && !h->certk && !h->reusek && !h->cfg.use_lds && h->ppt == 1 && h->shard.axis < 0 &&
            h->block_world == 1 && h->n_blocks > 0 && h->n_blocks + h->n_scans <= limit;      // (+ one helper workgroup per scan)
 }
 
@@ -878,6 +879,13 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     h->split = ppt == 1 && !h->cfg.use_lds && h->cfg.profile != 2 && h->cfg.pipeline == 2;
     // cfg.pipeline = 3: the fused launch with the certificate inside (k_s2m_iterate_cert, lio_cert.hip)
     h->certk = ppt == 1 && !h->cfg.use_lds && h->cfg.profile != 2 && h->cfg.pipeline == 3;
+    // cfg.pipeline = 5: the fused launch that keeps a point's plane while its ordered neighbour tuple stays the same (lio_reuse.hip)
+    h->reusek = ppt == 1 && !h->cfg.use_lds && h->cfg.profile != 2 && h->cfg.pipeline == 5;
+    if (h->reusek) {
+        HIPCHK(lio_grow(&h->d_cache_idx, &h->cap_cache_idx, tt * LIO_CACHE_K));
+        HIPCHK(lio_grow(&h->d_plane, &h->cap_plane, tt));
+        HIPCHK(lio_grow(&h->d_plane_state, &h->cap_plane_state, tt));
+    }
     if (h->split || h->certk) {
         HIPCHK(lio_grow(&h->d_cache_idx, &h->cap_cache_idx, tt * LIO_CACHE_K));
         HIPCHK(lio_grow(&h->d_cache_q, &h->cap_cache_q, tt));
@@ -1324,6 +1332,10 @@ static void lio_launch_gn(lio_s2m_handle* h, const LioIterParams& P, const LioIt
         lio_fill_split(h, P, S);
         S.it.d5_cache = nullptr;
         lio_launch_iterate_cert(S, h->n_blocks, h->stream);
+    } else if (h->reusek) {
+        LioSplitParams S;
+        lio_fill_split(h, P, S);
+        lio_launch_iterate_reuse(S, h->n_blocks, h->stream);
     } else {
         lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
     }
@@ -1347,6 +1359,10 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     h->pose_in_state = false;          // (d_poses holds the guess from now on)
     if (h->split && h->cfg.profile && h->d_split_stats)
         HIPCHK(hipMemsetAsync(h->d_split_stats, 0, h->v_groups.size() * LIO_MAX_ITERS * sizeof(int), h->stream));
+    if (h->reusek && h->cache_dirty) {
+        HIPCHK(hipMemsetAsync(h->d_plane_state, 0, (h->total_pts ? h->total_pts : 1) * sizeof(int), h->stream));
+        h->cache_dirty = false;
+    }
     if ((h->split || h->certk) && h->cache_dirty) {
         // 0xff bytes = NaN in the bound word: "no cache" (the `>= 0` test fails)
         HIPCHK(hipMemsetAsync(h->d_cache_q, 0xff, (h->total_pts ? h->total_pts : 1) * sizeof(float4), h->stream));
@@ -1711,7 +1727,7 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
     }
     h->prof.n_units = n_units;
     h->prof.unit_iters = h->unit_iters;
-    h->prof.pipeline = h->split ? 2 : (h->certk ? 3 : (h->run_persist ? 4 : 1));
+    h->prof.pipeline = h->split ? 2 : (h->certk ? 3 : (h->run_persist ? 4 : (h->reusek ? 5 : 1)));
     memset(h->prof.cert_points, 0, sizeof(h->prof.cert_points));
     memset(h->prof.scan_points, 0, sizeof(h->prof.scan_points));
     if (h->split && h->cfg.profile && h->d_split_stats && !h->v_groups.empty()) {

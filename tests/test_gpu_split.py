@@ -36,7 +36,7 @@ def _same(a, b):
                                           y.view(np.uint8) if y.dtype == np.uint8 else y.view(np.uint32))
 
 
-@pytest.mark.parametrize("pipe", [2, 3])
+@pytest.mark.parametrize("pipe", [2, 3, 5])
 @pytest.mark.parametrize("rec", [0, 1, 2, 4, 7])
 def test_split_equals_fused_every_iteration(pkg, oracle, small_case, rec, pipe):
     for q in small_case["queries"][:2]:
@@ -57,7 +57,7 @@ def test_split_equals_fused_every_iteration(pkg, oracle, small_case, rec, pipe):
             assert scanned[5:9].sum() < 0.25 * cert[5:9].sum(), (cert, scanned)
 
 
-@pytest.mark.parametrize("pipe", [2, 3])
+@pytest.mark.parametrize("pipe", [2, 3, 5])
 @pytest.mark.parametrize("variant", [dict(cell_div=1), dict(cell_div=3, sort_scan=0), dict(sort_scan=2), dict(cell_size=1.7),
                                      dict(jacobian_mode=1), dict(xcd_remap=0)])
 def test_split_variants(pkg, small_case, variant, pipe):
@@ -67,7 +67,7 @@ def test_split_variants(pkg, small_case, variant, pipe):
           _run(pkg, small_case["map"], q["scan"], q["pose_init"], pipeline=pipe, **kw))
 
 
-@pytest.mark.parametrize("pipe", [2, 3])
+@pytest.mark.parametrize("pipe", [2, 3, 5])
 def test_split_on_a_lattice_of_tied_distances(pkg, oracle, pipe):
     """Exactly equal distances everywhere (0.5 m lattice, duplicated points, scan points ON map points) while
     the pose creeps by millimetres: the certificate may only fire when no outsider can TIE with the 5th."""
@@ -89,7 +89,7 @@ def test_split_on_a_lattice_of_tied_distances(pkg, oracle, pipe):
         np.testing.assert_array_equal(split[3][0], corr[0])
 
 
-@pytest.mark.parametrize("pipe", [2, 3])
+@pytest.mark.parametrize("pipe", [2, 3, 5])
 @pytest.mark.parametrize("graph_iters", [0, 3, 30])
 def test_split_batches_and_hipgraph(pkg, small_case, graph_iters, pipe):
     qs = small_case["queries"]
@@ -119,7 +119,7 @@ def test_split_batches_and_hipgraph(pkg, small_case, graph_iters, pipe):
     ref.close(); s.close()
 
 
-@pytest.mark.parametrize("pipe", [2, 3])
+@pytest.mark.parametrize("pipe", [2, 3, 5])
 @pytest.mark.parametrize("offset", [(5000.0, -3000.0, 120.0), (-65536.0, 131072.0, 0.0)])
 def test_split_large_coordinates(pkg, offset, pipe):
     """UTM-like offsets (fp32 spacing up to 1.6 cm): the certificate's margins are relative to distances, not
