@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LIO_VERSION 100
+#define LIO_VERSION 101
 #define LIO_MAX_ITERS 32
 
 /* status codes */
@@ -93,13 +93,11 @@ typedef struct lio_s2m_config {
                                 is set -- the whole loop as ONE launch (k_s2m_persist: per-scan barrier between
                                 iterations; 0.17 against 0.25 ms per registration on MI355X); 1 = always one launch per
                                 iteration; 4 = the one-launch loop for every batch of at most one workgroup per compute
-                                unit; 2 = split: neighbour certificate / candidate scan / fit as three launches; 3 = the
-                                per-iteration launch with the certificate inside (k_s2m_iterate_cert); 5 = the
-                                per-iteration launch that keeps a point's plane while its neighbour tuple stands
-                                (k_s2m_iterate_reuse); 2 and 5 measured slower and 3 no faster, all three kept as
-                                options with their evidence                                                              */
+                                unit.  Other values are refused (2, 3 and 5 were per-point-cache experiments of round 2,
+                                measured slower or equal and removed: DESIGN.md appendix)                                */
     int32_t n_devices;       /* 1 (default) = the single device `device_id`.  > 1: in-library multi-GPU -- the local
-                                map is cut into slabs (+ one-cell halo) over device_ids[0..n_devices), every
+                                map is cut into slabs (+ a halo of 16 cells, i.e. ~16 m of extra map per side and
+                                device) over device_ids[0..n_devices), every
                                 registration's points are processed by the device owning their map cell and the
                                 6x6 JtJ / 6x1 Jtr / N_c are summed across the devices once per GN iteration
                                 (the join of the OpenMP loop MO:1622-1686); set_map / register / batch_* work
@@ -133,11 +131,14 @@ typedef struct lio_s2m_profile {
     int64_t point_iters;       /* scan points processed by active scans over the run      */
     int64_t n_map;             /* resident map points                                     */
     int64_t n_cells;           /* grid cells                                              */
-    int32_t pipeline;          /* what the last run used: 1 = one launch per iteration, 2 = split, 3 = certificate inside, 4 = one-launch loop */
-    int32_t pad_;
-    int64_t cert_points[LIO_MAX_ITERS]; /* split pipeline, per GN iteration: scan points looked at by the
-                                  neighbour certificate ...                               */
-    int64_t scan_points[LIO_MAX_ITERS]; /* ... and those that still needed a candidate scan */
+    int32_t pipeline;          /* what the last run used: 1 = one launch per iteration, 4 = one-launch loop */
+    int32_t multi_iterations;  /* in-library multi-GPU mode (cfg.n_devices > 1), last run: GN iterations enqueued,        */
+    int32_t multi_stream_syncs;/* ... stream / device synchronisations issued inside the loop (0 with the device-side
+                                  exchange) and                                                                        */
+    int32_t multi_event_waits; /* ... waits for a convergence count (an event wait, `lookahead` iterations behind)      */
+    int32_t multi_exchange;    /* ... 0 = peer stores from a kernel, 1 = hipMemcpyPeerAsync, 2 = through host memory    */
+    int32_t persist_fallbacks; /* one-launch loops of this handle that timed out at a barrier and were re-run through the
+                                  launch loop inside the same call (cumulative; see lio_s2m_batch_results)              */
 } lio_s2m_profile;
 
 typedef struct lio_s2m_handle lio_s2m_handle;
@@ -225,6 +226,11 @@ int  lio_s2m_get_corner_correspondences(lio_s2m_handle *h, int32_t scan, uint8_t
                                         float *coeff4, int32_t *nn_idx5);
 
 int  lio_s2m_get_profile(lio_s2m_handle *h, lio_s2m_profile *out);
+/* Test hook for the one-launch loop (cfg.pipeline 0 / 4): spin_max = polls before a workgroup waiting at its scan's barrier
+ * gives up (0 = default: 4096, a few milliseconds; LIO_PERSIST_SPIN_MAX in the environment), withhold_wg = index of an
+ * association workgroup that never arrives (-1 = none).  A launch that times out is re-run through the launch loop inside
+ * lio_s2m_batch_results / lio_s2m_register and counted in lio_s2m_profile.persist_fallbacks; results are the same. */
+int  lio_s2m_debug_persist_spin(lio_s2m_handle *h, int32_t spin_max, int32_t withhold_wg);
 /* Diagnostic (cfg.profile == 2): per-wave phase clock of the last GN launch,
  * n_blocks x 4 x 8 cycle counters; returns n_blocks.  Not for production. */
 int  lio_s2m_debug_stamps(lio_s2m_handle *h, long long *out, size_t cap_entries);
@@ -324,6 +330,18 @@ typedef struct lio_pc2_layout {
  * pcl::fromROSMsg MO:440 + the loop MO:1848-1859.  Only off_x / point_step / pin_host of the layout are used. */
 int  lio_s2m_register_pc2(lio_s2m_handle *h, const void *data, size_t n_points, const lio_pc2_layout *layout,
                           float pose[6], lio_s2m_result *res);
+/* One mapping callback on the device: downsampleCurrentScan MO:1605-1611 (`downSizeFilterSurf.filter`, leaf =
+ * mappingSurfLeafSize) + scan2MapOptimization MO:1839-1865 on the blob of cloud_info.cloud_deskewed (MO:440), without a host
+ * round trip in between: one H2D copy of the blob (true DMA with layout->pin_host or lio_host_alloc memory; none when
+ * `data` already is memory of the handle's device), the voxel filter on the handle's stream with its workspace kept on
+ * the handle, the Gauss-Newton loop on the filter's output where it lies.  Bit-identical to lio_voxel_grid followed by
+ * lio_s2m_register on its output (including PCL's pass-through when the leaf overflows the voxel index: the function
+ * then still registers the unfiltered cloud, as the reference does).  off_x / off_intensity / point_step / pin_host of the
+ * layout are used.  ds_out (may be NULL): receives laserCloudSurfLastDS as PointXYZI-compatible records, room for
+ * n_points; *n_ds (may be NULL) = its size.  The filtered cloud stays staged on the handle: lio_kf_store_add_from_handle
+ * (h, 0) makes it a keyframe (MO:2136-2142) without a copy through the host. */
+int  lio_s2m_register_raw(lio_s2m_handle *h, const void *data, size_t n_points, const lio_pc2_layout *layout, float leaf,
+                          float pose[6], lio_s2m_result *res, void *ds_out, size_t ds_out_stride, size_t *n_ds);
 /* lio_deskew on the raw driver message (IP:214-232 + IP:577-615).  out: PointXYZI-compatible records as for lio_deskew. */
 int  lio_deskew_pc2(const lio_deskew_config *cfg, const void *data, size_t n_points, const lio_pc2_layout *layout,
                     double time_scan_cur,

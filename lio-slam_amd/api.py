@@ -54,8 +54,8 @@ class S2MProfile(C.Structure):
         ("launch_ms", C.c_float * LIO_MAX_ITERS), ("launch_active", C.c_int32 * LIO_MAX_ITERS),
         ("point_iters", C.c_int64),
         ("n_map", C.c_int64), ("n_cells", C.c_int64),
-        ("pipeline", C.c_int32), ("pad_", C.c_int32),
-        ("cert_points", C.c_int64 * LIO_MAX_ITERS), ("scan_points", C.c_int64 * LIO_MAX_ITERS),
+        ("pipeline", C.c_int32), ("multi_iterations", C.c_int32), ("multi_stream_syncs", C.c_int32),
+        ("multi_event_waits", C.c_int32), ("multi_exchange", C.c_int32), ("persist_fallbacks", C.c_int32),
     ]
 
 
@@ -123,6 +123,7 @@ EXPORTS = [
     "lio_range_image_default_config", "lio_range_image",
     "lio_s2m_share_map", "lio_s2m_batch_upload_async", "lio_host_alloc", "lio_host_free", "lio_host_register",
     "lio_host_unregister", "lio_s2m_set_shard_plan", "lio_s2m_register_pc2", "lio_deskew_pc2", "lio_kf_store_add_device", "lio_kf_store_add_from_handle",
+    "lio_s2m_register_raw", "lio_s2m_debug_persist_spin",
 ]
 
 
@@ -147,6 +148,8 @@ def load_library():
     L.lio_s2m_set_map.argtypes = [vp, vp, sz, sz]
     L.lio_s2m_register.argtypes = [vp, vp, sz, sz, C.POINTER(f32), C.POINTER(S2MResult)]
     L.lio_s2m_register_pc2.argtypes = [vp, vp, sz, C.POINTER(PC2Layout), C.POINTER(f32), C.POINTER(S2MResult)]
+    L.lio_s2m_register_raw.argtypes = [vp, vp, sz, C.POINTER(PC2Layout), f32, C.POINTER(f32), C.POINTER(S2MResult), vp, sz, C.POINTER(sz)]
+    L.lio_s2m_debug_persist_spin.argtypes = [vp, i32, i32]
     L.lio_s2m_batch_upload.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), sz]
     L.lio_s2m_batch_upload_async.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), sz]
     L.lio_s2m_share_map.argtypes = [vp, vp]
@@ -287,6 +290,26 @@ class ScanToMap:
         self._n_scans, self._npts = 1, [n_points]
         return p, res, rc
 
+    # downsampleCurrentScan MO:1605-1611 + scan2MapOptimization MO:1839-1865 on the blob of cloud_info.cloud_deskewed,
+    # one H2D copy, no host round trip between the voxel filter and the registration
+    def downsampleAndScan2MapOptimization(self, blob, n_points, layout, leaf, pose, want_ds=False, device_ptr=None):
+        p = np.array(pose, np.float32).copy()
+        res = S2MResult()
+        if device_ptr is None:
+            b = np.ascontiguousarray(blob).view(np.uint8).reshape(-1)
+            ptr = b.ctypes.data
+        else:
+            ptr = int(device_ptr)
+        out = np.zeros((n_points, 8), np.float32) if want_ds else None
+        n_ds = C.c_size_t(0)
+        rc = _check(self.lib.lio_s2m_register_raw(self.h, ptr, n_points, C.byref(layout), float(leaf), _f32p(p), C.byref(res),
+                                                  out.ctypes.data if want_ds else None, 32, C.byref(n_ds)), "lio_s2m_register_raw")
+        self._n_scans, self._npts = 1, [int(n_ds.value)]
+        if want_ds:
+            o = out[:n_ds.value]
+            return p, res, rc, np.concatenate([o[:, :3], o[:, 4:5]], 1)
+        return p, res, rc, int(n_ds.value)
+
     # batched form
     def batch_upload(self, scans):
         arrs = [_as_points(s) for s in scans]
@@ -384,6 +407,10 @@ class ScanToMap:
         p = S2MProfile()
         _check(self.lib.lio_s2m_get_profile(self.h, C.byref(p)), "lio_s2m_get_profile")
         return p
+
+    def debug_persist_spin(self, spin_max=0, withhold_wg=-1):
+        """Test hook of the one-launch loop: poll bound and a workgroup that never arrives (include/liogpu.h)."""
+        _check(self.lib.lio_s2m_debug_persist_spin(self.h, int(spin_max), int(withhold_wg)), "lio_s2m_debug_persist_spin")
 
     def debug_stamps(self):
         nb = self.lib.lio_s2m_debug_stamps(self.h, None, 0)

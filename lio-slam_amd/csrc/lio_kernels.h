@@ -34,25 +34,6 @@ struct LioIterParams {
                                    // for by the cull, 2 wholly ours), or null
 };
 
-// Arguments of the split pipeline's kernels: the fused kernel's plus the neighbour cache and the work list.
-struct LioSplitParams {
-    LioIterParams it;
-    // ---- split pipeline (cfg.pipeline): neighbour cache and the per-iteration scan work list
-    const LioGroupDesc* groups;    // certificate workgroups
-    int n_groups;
-    int* cache_idx;                // [total_pts][LIO_CACHE_K] map indices (caller order), nearest first after a scan / a certificate; -1 = none
-    float4* cache_q;               // [total_pts] (position the cache was built at, w = lower bound on the distance from
-                                   //  there to every map point NOT in the cache; w < 0: no cache)
-    int* pt_flag;                  // [total_pts] this iteration: 0 = no plane candidate, 1 = cache_idx[0..4] is the 5-NN (gate passed), 2 = scan pending
-    float* scan_bound2;            // [total_pts] squared search bound of a pending scan
-    int* scan_list;                // [total_pts] per group: slots with a pending scan, longest candidate run first
-    int* scan_cnt;                 // [n_groups]
-    float4* plane;                 // [total_pts] k_s2m_iterate_cert: the plane (pa,pb,pc,pd) fitted to cache_idx[0..4] in that order
-    int* plane_state;              // [total_pts] 0 = none, 1 = plane kept and valid (MO:1658-1666), 2 = kept, not valid
-    int* stats;                    // [32][n_groups] diagnostics: candidate scans queued by each group in each GN iteration, or null
-    int sort_mode;                 // order of a group's work list (see k_s2m_cert)
-};
-
 void lio_launch_aos_to_soa(const void* src, size_t stride, int n, float* x, float* y, float* z,
                            float4* xyz4, hipStream_t s);
 void lio_launch_map_bbox(const float* x, const float* y, const float* z, int n, unsigned* bbox, hipStream_t s);
@@ -63,13 +44,10 @@ int  lio_scan_tiles(int n_cells);
 void lio_launch_init_state(LioScanState* st, int n_scans, float* poses, bool from_state, const LioConsts& c,
                            int* n_active, hipStream_t s);
 void lio_launch_iterate(const LioIterParams& P, int n_blocks, int ppt, bool stage, hipStream_t s, bool corner = false);
-void lio_launch_split_iteration(const LioSplitParams& S, int n_blocks, hipStream_t s);
-void lio_launch_iterate_cert(const LioSplitParams& S, int n_blocks, hipStream_t s);
-void lio_launch_iterate_reuse(const LioSplitParams& S, int n_blocks, hipStream_t s);
 void lio_launch_persist(const LioIterParams& P, int n_blocks, unsigned* gen, unsigned epoch, const unsigned char* stage, size_t stride,
-                        int n_scans, unsigned* spec, double* spec_sums, const float* poses0, hipStream_t s);
+                        int n_scans, unsigned* spec, double* spec_sums, const float* poses0, unsigned spin_max, int withhold_wg, hipStream_t s);
 void lio_launch_pack_summary(const LioScanState* st, int n_scans, float* out, hipStream_t s);
-void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
+void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, size_t slot_stride, int n_slots, const LioConsts& c,
                       int* n_active, hipStream_t s);
 void lio_launch_shard_cull(const LioIterParams& P, int n_ranks, int rank, int halo, const int* bounds, const float* block_box,
                            int n_blocks, unsigned char* skip, hipStream_t s);

@@ -1091,15 +1091,26 @@ __global__ void k_s2m_pack_summary(const LioScanState* __restrict__ st, int n_sc
     o[8] = __int_as_float(st[s].converged); o[9] = __int_as_float(st[s].is_degenerate);
 }
 
-// Sharded mode: solve every scan from all-reduced sums (one wave per scan).
-__global__ void k_s2m_apply(LioScanState* __restrict__ st, int n_scans, const double* __restrict__ sums, LioConsts c,
-                            int* __restrict__ n_active)
+// Sharded mode: solve every scan from all-reduced sums (one wave per scan).  n_slots > 1: the sums arrive as one partial
+// table per device (slot d at sums + d * slot_stride, in-library multi-GPU mode) and are added here in slot order --
+// the same order on every device, so every device computes bit-identical poses.
+__global__ void k_s2m_apply(LioScanState* __restrict__ st, int n_scans, const double* __restrict__ sums, size_t slot_stride, int n_slots,
+                            LioConsts c, int* __restrict__ n_active)
 {
     const int s = blockIdx.x;                                // one wave per scan
     if (s >= n_scans) return;
     if (st[s].done) return;
     __shared__ LioSolveWs s_ws;
-    lio_gn_step(&st[s], sums + (size_t)s * LIO_SUMS, c, &s_ws, n_active, (int)threadIdx.x);
+    __shared__ double s_tot[LIO_SUMS];
+    const int lane = (int)threadIdx.x;
+    if (lane < LIO_SUMS) {
+        const double* p = sums + (size_t)s * LIO_SUMS + lane;
+        double v = p[0];
+        for (int d = 1; d < n_slots; ++d) v += p[(size_t)d * slot_stride];
+        s_tot[lane] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // one wave: the sums are in LDS before any lane reads them
+    lio_gn_step(&st[s], s_tot, c, &s_ws, n_active, lane);
 }
 
 // ------------------------------------------------------------ launch glue
@@ -1197,10 +1208,10 @@ void lio_launch_pack_summary(const LioScanState* st, int n_scans, float* out, hi
     hipLaunchKernelGGL(k_s2m_pack_summary, dim3((n_scans + 255) / 256), dim3(256), 0, s, st, n_scans, out);
 }
 
-void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, const LioConsts& c,
+void lio_launch_apply(LioScanState* st, int n_scans, const double* sums, size_t slot_stride, int n_slots, const LioConsts& c,
                       int* n_active, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_s2m_apply, dim3(n_scans), dim3(64), 0, s, st, n_scans, sums, c, n_active);
+    hipLaunchKernelGGL(k_s2m_apply, dim3(n_scans), dim3(64), 0, s, st, n_scans, sums, slot_stride, n_slots, c, n_active);
 }
 
 void lio_launch_shard_cull(const LioIterParams& P, int n_ranks, int rank, int halo, const int* bounds, const float* block_box,

@@ -9,8 +9,7 @@
 #include <string.h>
 #include <vector>
 
-#include "../../include/liogpu.h"
-#include "lio_kernels.h"
+#include "lio_handle.h"
 #include "lio_pool.h"
 #include "lio_device_math.h"
 #include "lio_scan2.h"
@@ -20,12 +19,6 @@ int lio_s2m_set_map_device_xyzi(lio_s2m_handle* h, const float4* d_xyzi, size_t 
 int lio_s2m_set_map_device_bbox(lio_s2m_handle* h, const float4* d_xyzi, size_t n, const float box[6]);
 hipStream_t lio_s2m_stream_of(lio_s2m_handle* h);
 bool lio_s2m_takes_device_map(const lio_s2m_handle* h);
-
-#define HIPCHK(expr)                                                              \
-    do {                                                                          \
-        hipError_t _e = (expr);                                                   \
-        if (_e != hipSuccess) return lio_fail_ext(LIO_ERR_HIP, #expr, _e);        \
-    } while (0)
 
 struct LioKfDesc {       // one selected keyframe
     int src;             // first point of the keyframe in the resident store
@@ -597,15 +590,15 @@ static void kf_store_commit(lio_kf_store* s, size_t n, int32_t* id_out)
     s->used += n;
 }
 
-// records (x,y,z at xyz_off, intensity at byte 16 when the record has one) -> float4 (x,y,z,intensity)
-__global__ void k_rec_to_xyzi4(const unsigned char* __restrict__ src, size_t stride, size_t xyz_off, int has_intensity, int n,
+// records (x,y,z at xyz_off, FLOAT32 intensity at int_off, < 0 = the record carries none) -> float4 (x,y,z,intensity)
+__global__ void k_rec_to_xyzi4(const unsigned char* __restrict__ src, size_t stride, size_t xyz_off, int int_off, int n,
                                float4* __restrict__ dst)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned char* rec = src + (size_t)i * stride;
     const float* p = reinterpret_cast<const float*>(rec + xyz_off);
-    dst[i] = make_float4(p[0], p[1], p[2], has_intensity ? *reinterpret_cast<const float*>(rec + 16) : 0.0f);
+    dst[i] = make_float4(p[0], p[1], p[2], int_off >= 0 ? *reinterpret_cast<const float*>(rec + int_off) : 0.0f);
 }
 
 extern "C" int lio_kf_store_add(lio_kf_store* s, const void* cloud, size_t n, size_t stride, int32_t* id_out)
@@ -638,7 +631,7 @@ extern "C" int lio_kf_store_add_device(lio_kf_store* s, const void* d_cloud, siz
     if (n) {
         HIPCHK(hipDeviceSynchronize());                  // the producer of d_cloud may have used any stream
         hipLaunchKernelGGL(k_rec_to_xyzi4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
-                           (const unsigned char*)d_cloud, stride, (size_t)0, stride >= 20 ? 1 : 0, (int)n, s->d_pts + s->used);
+                           (const unsigned char*)d_cloud, stride, (size_t)0, stride >= 20 ? 16 : -1, (int)n, s->d_pts + s->used);
         HIPCHK(hipStreamSynchronize(nullptr));
         HIPCHK(hipGetLastError());
     }
@@ -646,7 +639,7 @@ extern "C" int lio_kf_store_add_device(lio_kf_store* s, const void* d_cloud, siz
     return LIO_OK;
 }
 
-int lio_s2m_staged_scan(lio_s2m_handle* h, int scan, const unsigned char** d_rec, size_t* n, size_t* stride, size_t* xyz_off,
+int lio_s2m_staged_scan(lio_s2m_handle* h, int scan, const unsigned char** d_rec, size_t* n, size_t* stride, size_t* xyz_off, int* int_off,
                         int* device_id, hipStream_t* stream);   // liogpu_api.hip
 
 extern "C" int lio_kf_store_add_from_handle(lio_kf_store* s, lio_s2m_handle* h, int32_t scan, int32_t* id_out)
@@ -654,17 +647,17 @@ extern "C" int lio_kf_store_add_from_handle(lio_kf_store* s, lio_s2m_handle* h, 
     if (!s || !h) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
     const unsigned char* rec = nullptr;
     size_t n = 0, stride = 0, xyz_off = 0;
-    int dev = 0;
+    int dev = 0, int_off = -1;
     hipStream_t st = nullptr;
-    int rc = lio_s2m_staged_scan(h, scan, &rec, &n, &stride, &xyz_off, &dev, &st);
+    int rc = lio_s2m_staged_scan(h, scan, &rec, &n, &stride, &xyz_off, &int_off, &dev, &st);
     if (rc != LIO_OK) return rc;
     if (dev != s->device_id) return lio_fail_ext(LIO_ERR_ARG, "the handle and the keyframe store live on different devices", hipSuccess);
     if ((rc = check_device(s->device_id)) != LIO_OK) return rc;
     if ((rc = kf_store_reserve(s, n)) != LIO_OK) return rc;
     if (n) {
-        // (PCL-style records keep the intensity at byte 16; packed xyz / xyzi-at-12 records carry none there)
-        const int has_i = (xyz_off == 0 && stride >= 20) ? 1 : 0;
-        hipLaunchKernelGGL(k_rec_to_xyzi4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rec, stride, xyz_off, has_i, (int)n,
+        // the intensity sits where the upload said it does (lio_pc2_layout.off_intensity; byte 16 for PCL records; byte 12 for
+        // the float4 records lio_s2m_register_raw stages), not at a guessed offset
+        hipLaunchKernelGGL(k_rec_to_xyzi4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rec, stride, xyz_off, int_off, (int)n,
                            s->d_pts + s->used);
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
@@ -773,4 +766,82 @@ extern "C" int lio_assemble_map(lio_s2m_handle* h, int32_t device_id, int32_t n_
     if (rc == LIO_OK) rc = lio_assemble_map_resident(h, st, n_kf, ids.data(), poses, leaf, out, out_stride, n_out);
     lio_kf_store_destroy(st);
     return rc;
+}
+
+
+// ------------------------------------------------ one callback on the device: downsample + register (SURVEY 8f / verdict r2)
+// Staged cloud and voxel-filter workspace of lio_s2m_register_raw, kept on the handle from one callback to the next.
+struct LioRawWs {
+    LioKeep raw, xyzi, ds;
+    LioVoxWs<LioKeep> vws;
+};
+
+void lio_raw_ws_free(LioRawWs* w)
+{
+    if (!w) return;
+    LioKeep* keep[] = { &w->raw, &w->xyzi, &w->ds, &w->vws.bbox, &w->vws.key_of, &w->vws.slot_of, &w->vws.count, &w->vws.start, &w->vws.rank,
+                        &w->vws.tiles, &w->vws.tmp, &w->vws.list, &w->vws.large };
+    for (LioKeep* k : keep) k->release();
+    delete w;
+}
+
+// downsampleCurrentScan MO:1605-1611 + scan2MapOptimization MO:1839-1865 without a host round trip in between:
+// the deskewed cloud goes up once (or is read in place when it already lives on the device), is voxel-filtered on the
+// handle's stream with the workspace kept on the handle, and the Gauss-Newton loop runs on the filter's output where it
+// lies (float4 x,y,z,intensity records).  The result is bit-identical to lio_voxel_grid followed by lio_s2m_register
+// on its output: same filter code, same registration code.  The filtered cloud stays staged on the handle, so
+// lio_kf_store_add_from_handle turns it into a keyframe (saveKeyFramesAndFactor MO:2136-2142) with its intensities.
+extern "C" int lio_s2m_register_raw(lio_s2m_handle* h, const void* data, size_t n_points, const lio_pc2_layout* layout, float leaf,
+                                    float pose[6], lio_s2m_result* res, void* ds_out, size_t ds_out_stride, size_t* n_ds)
+{
+    if (!h || !layout || !pose) return lio_fail_ext(LIO_ERR_ARG, "null argument", hipSuccess);
+    if (h->multi || h->corner_active) return lio_fail_ext(LIO_ERR_ARG, "lio_s2m_register_raw needs a plain single-device handle", hipSuccess);
+    if (lio_pc2_check_xyz(layout) != LIO_OK) return LIO_ERR_ARG;
+    if (!(leaf > 0.0f)) return lio_fail_ext(LIO_ERR_ARG, "leaf must be positive", hipSuccess);
+    if (ds_out && (ds_out_stride < 20 || (ds_out_stride & 3))) return lio_fail_ext(LIO_ERR_ARG, "output stride must be >= 20 and a multiple of 4", hipSuccess);
+    if (n_points && !data) return lio_fail_ext(LIO_ERR_ARG, "null cloud", hipSuccess);
+    if (n_points > 0x7fffffffull - 1024) return lio_fail_ext(LIO_ERR_CAPACITY, "cloud too large", hipSuccess);
+    if (n_ds) *n_ds = 0;
+    int rc = check_device(h->cfg.device_id);
+    if (rc != LIO_OK) return rc;
+    if (!h->raw_ws) h->raw_ws = new LioRawWs();
+    LioRawWs* w = h->raw_ws;
+    hipStream_t s = h->stream;
+    const size_t step = layout->point_step, n = n_points;
+    // the blob: read in place when it is device memory of this device, else one H2D copy (a true DMA when pinned)
+    const unsigned char* d_rec = nullptr;
+    bool pinned = false;
+    if (n) {
+        hipPointerAttribute_t at;
+        bool in_place = false;
+        if (hipPointerGetAttributes(&at, data) == hipSuccess) in_place = at.type == hipMemoryTypeDevice && at.device == h->cfg.device_id;
+        (void)hipGetLastError();                         // (pageable host memory is reported as an error)
+        if (in_place) {
+            d_rec = (const unsigned char*)data;
+        } else {
+            if (layout->pin_host) {
+                pinned = hipHostRegister(const_cast<void*>(data), n * step, hipHostRegisterDefault) == hipSuccess;
+                (void)hipGetLastError();
+            }
+            HIPCHK(w->raw.alloc(n * step));
+            HIPCHK(hipMemcpyAsync(w->raw.p, data, n * step, hipMemcpyHostToDevice, s));
+            d_rec = w->raw.as<unsigned char>();
+        }
+        HIPCHK(w->xyzi.alloc(n * sizeof(float4)));
+        hipLaunchKernelGGL(k_rec_to_xyzi4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_rec, step, (size_t)layout->off_x,
+                           layout->off_intensity >= 0 ? layout->off_intensity : -1, (int)n, w->xyzi.as<float4>());
+    }
+    int no = 0;
+    // (the filter's first host wait -- the bounding box -- also covers the H2D copy: the caller's blob is free again)
+    rc = voxel_grid_device<LioKeep>(w->xyzi.as<float4>(), (int)n, leaf, w->ds, &no, s, w->vws, false, nullptr);
+    if (pinned) (void)hipHostUnregister(const_cast<void*>(data));
+    if (rc < 0) return rc;                               // (rc == 1: PCL would pass the cloud through -- and so did we)
+    if (n == 0) HIPCHK(w->ds.alloc(sizeof(float4)));
+    h->int_off = 12;                                     // the staged records are float4 (x, y, z, intensity)
+    const int rr = lio_s2m_register(h, w->ds.p, (size_t)no, sizeof(float4), pose, res);
+    h->int_off = -2;
+    if (rr < 0) return rr;
+    if (ds_out) { const int rc2 = copy_out(w->ds.as<float4>(), no, ds_out, ds_out_stride, s); if (rc2 < 0) return rc2; }
+    if (n_ds) *n_ds = (size_t)no;
+    return rr;
 }

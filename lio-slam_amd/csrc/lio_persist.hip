@@ -8,9 +8,12 @@
 // of scan s only wait for scan s's solve.  The solving wave re-arms the arrival counter, releases (agent scope: its
 // XCD's L2 is written back) and publishes gen[s] = iterations done; wave 0 of every other workgroup of the scan polls
 // gen[s] (epoch + iterations done, so that nothing needs clearing between runs) with write-through loads, then the whole workgroup acquires (L1 / non-local L2 lines invalidated) and re-reads
-// the scan's state.  Every poll loop is bounded: after LIO_PERSIST_SPIN_MAX polls the workgroup leaves with the
-// scan's `done` flag still clear, so every wave reaches an exit whatever happens (the host finds a scan that is not done
-// after the launch and reports LIO_ERR_HIP).
+// the scan's state.  Every poll loop is bounded: after `spin_max` polls (a few milliseconds) the workgroup leaves with the
+// scan's `done` flag still clear, so every wave reaches an exit whatever happens -- the workgroups of a launch are only
+// guaranteed to make progress together when they are all resident, which another client of the GPU can prevent.  The host
+// finds a scan that is not done after the launch, clears the arrival counters and runs the SAME registration through the
+// launch loop from the saved initial guess inside the same call (lio_s2m_batch_results; counted in
+// lio_s2m_profile.persist_fallbacks): a contended GPU costs a few milliseconds, never a wrong or missing result.
 //
 // Speculation on isDegenerate.  The first solve of a registration carries cv::eigen for isDegenerate / matP (MO:1786-1808),
 // ~36 us of Jacobi rotations that the next pose formally depends on -- but only if a direction IS degenerate.  So the
@@ -29,12 +32,11 @@
 #include "lio_device_math.h"
 #include "lio_s2m_device.h"
 
-#define LIO_PERSIST_SPIN_MAX (1u << 19)      // ~1 s of polling (a poll is a sleep + one L2-bypassing load)
-
 namespace {
 
 __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, unsigned* __restrict__ gen, unsigned epoch, const unsigned char* __restrict__ stage, unsigned stride,
-                   int n_main, unsigned* __restrict__ spec, double* __restrict__ spec_sums, const float* __restrict__ poses0)
+                   int n_main, unsigned* __restrict__ spec, double* __restrict__ spec_sums, const float* __restrict__ poses0,
+                   unsigned spin_max, int withhold_wg)
 {
     __shared__ __attribute__((aligned(16))) double s_rows[LIO_BLOCK][8];
     __shared__ double s_part[8][28];
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
             const int v = (int)(__hip_atomic_load(&spec[scan], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch);
             if (v >= 1) break;                             // asked
             if (__hip_atomic_load(&hs->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // the registration ended without asking
-            if (++spins > LIO_PERSIST_SPIN_MAX * 2u) return;
+            if (++spins > spin_max * 2u) return;
             __builtin_amdgcn_s_sleep(8);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
         if (hl == 0) __hip_atomic_store(&spec[scan], epoch + 2u + (unsigned)deg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+    if (wg == withhold_wg) return;                         // test hook (lio_s2m_debug_persist_spin): this workgroup never arrives
     const LioBlockDesc bd = P.blocks[wg];
     LioScanState* st = &P.state[bd.scan];
     const LioGrid g = P.grid;
@@ -216,6 +219,9 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
                 for (int w = 1; w < 8; ++w) v += s_part[w][lane];
                 __hip_atomic_store(part + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
             }
+            // ORDERING: the 28 write-through (sc1) stores above have left this wave's vector-memory queue, i.e. they are
+            // complete at the agent-coherent level, before the arrival below can be observed -- the release half of the
+            // arrive protocol, for these stores only (cheaper than an agent-scope release fence, which writes back the whole L2)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             int last = 0;
             if (lane == 0) {
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
                     }
                     s_sum[lane] = v;
                 }
+                // ORDERING: the LDS writes of s_sum by lanes 0..27 are complete before lane 0 (same wave) reads them in lio_gn_step
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&P.arrive[bd.scan], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
                 // (solver detail of the phase clock, slots 8-14: gather / step / release of iteration 0 and of the later ones, solves counted)
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
                             unsigned spins = 0;
                             while (sp == 1) {
                                 sp = (int)(__hip_atomic_load(&spec[bd.scan], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch);
-                                if (++spins > LIO_PERSIST_SPIN_MAX) { lost = true; break; }
+                                if (++spins > spin_max) { lost = true; break; }
                                 __builtin_amdgcn_s_sleep(4);
                             }
                         }
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
             if (lane == 0) {
                 unsigned spins = 0;
                 while ((int)(__hip_atomic_load(&gen[bd.scan], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (epoch + (unsigned)(it + 1))) < 0) {
-                    if (++spins > LIO_PERSIST_SPIN_MAX) { ctl = 2; break; }
+                    if (++spins > spin_max) { ctl = 2; break; }
                     __builtin_amdgcn_s_sleep(4);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // pairs with the solver's release
@@ -329,16 +336,16 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
 
 }  // namespace
 
-// `epoch`: a number that grows by at least 128 from one launch on these buffers to the next (the generation numbers of a run
-// are epoch + 1 .. epoch + 32, compared modulo 2^32), so nothing has to be cleared between runs.
 // `epoch`: a number that grows by at least 128 from one launch on these buffers to the next (generation numbers and
 // speculation states of a run are epoch + small numbers, compared modulo 2^32), so nothing has to be cleared between runs.
 // spec != nullptr: n_scans helper workgroups follow the n_blocks association workgroups (see "Speculation" above).
+// spin_max: polls before a waiting workgroup gives up (a poll is a short sleep + one L2-bypassing load, ~1-2 us);
+// withhold_wg: test hook, -1 in production.
 void lio_launch_persist(const LioIterParams& P, int n_blocks, unsigned* gen, unsigned epoch, const unsigned char* stage, size_t stride,
-                        int n_scans, unsigned* spec, double* spec_sums, const float* poses0, hipStream_t s)
+                        int n_scans, unsigned* spec, double* spec_sums, const float* poses0, unsigned spin_max, int withhold_wg, hipStream_t s)
 {
     if (n_blocks <= 0) return;
     const int n_help = spec ? n_scans : 0;
     hipLaunchKernelGGL(k_s2m_persist, dim3(n_blocks + n_help), dim3(LIO_BLOCK), 0, s, P, gen, epoch, stage, (unsigned)stride,
-                       n_blocks, spec, spec_sums, poses0);
+                       n_blocks, spec, spec_sums, poses0, spin_max, withhold_wg);
 }

@@ -414,18 +414,20 @@ static const lio_pc2_layout kXyzirtLayout = { 32, 0, 16, 20, LIO_PC2_UINT16, 24,
 static int lio_check_layout(const lio_pc2_layout* L, bool need_ring)
 {
     if (!L) return lio_fail_ext(LIO_ERR_ARG, "null layout", hipSuccess);
+    // offsets come off the wire: every bound is written without an addition that could wrap in 32 bits
+    // (`off_x + 12 > st` passes for off_x = 0xfffffff4 -- round-2 advisor finding)
     const uint32_t st = L->point_step;
-    if (st < 12 || (L->off_x & 3) || L->off_x + 12 > st)
+    if (st < 12 || (L->off_x & 3) || L->off_x > st - 12)
         return lio_fail_ext(LIO_ERR_ARG, "x, y, z must be three consecutive FLOAT32 fields inside the record", hipSuccess);
-    if (L->off_intensity >= 0 && ((L->off_intensity & 3) || (uint32_t)L->off_intensity + 4 > st))
+    if (L->off_intensity >= 0 && ((L->off_intensity & 3) || (uint32_t)L->off_intensity > st - 4))
         return lio_fail_ext(LIO_ERR_ARG, "intensity must be an aligned FLOAT32 field inside the record", hipSuccess);
     if (need_ring) {
-        const int rs = L->ring_type == LIO_PC2_UINT8 ? 1 : (L->ring_type == LIO_PC2_UINT16 ? 2 : (L->ring_type == LIO_PC2_INT32 ? 4 : 0));
-        if (!rs || L->off_ring < 0 || (L->off_ring % rs) || (uint32_t)L->off_ring + rs > st)
+        const uint32_t rs = L->ring_type == LIO_PC2_UINT8 ? 1 : (L->ring_type == LIO_PC2_UINT16 ? 2 : (L->ring_type == LIO_PC2_INT32 ? 4 : 0));
+        if (!rs || L->off_ring < 0 || ((uint32_t)L->off_ring % rs) || (uint32_t)L->off_ring > st - rs)
             return lio_fail_ext(LIO_ERR_ARG, "ring must be an aligned UINT8 / UINT16 / INT32 field inside the record (IP:313-329)", hipSuccess);
         if (L->off_time >= 0) {
-            const int ts = L->time_type == LIO_PC2_TIME_F64_STAMP ? 8 : 4;
-            if (L->time_type < 0 || L->time_type > 3 || (L->off_time & 3) || (uint32_t)L->off_time + ts > st)
+            const uint32_t ts = L->time_type == LIO_PC2_TIME_F64_STAMP ? 8 : 4;
+            if (L->time_type < 0 || L->time_type > 3 || (L->off_time & 3) || st < ts || (uint32_t)L->off_time > st - ts)
                 return lio_fail_ext(LIO_ERR_ARG, "time field outside the record or of an unknown type", hipSuccess);
         }
     }

@@ -1,6 +1,5 @@
 // lio_s2m_device.h -- device code shared by the Gauss-Newton kernels of the scan-to-map path:
-// k_s2m_iterate (lio_kernels.hip, one fused launch per iteration) and k_s2m_cert / k_s2m_scan / k_s2m_fit
-// (lio_split.hip).  MO = /root/reference/src/liorf/src/mapOptmization.cpp.
+// k_s2m_iterate (lio_kernels.hip, one fused launch per iteration) and k_s2m_persist (lio_persist.hip, the whole loop in one launch).  MO = /root/reference/src/liorf/src/mapOptmization.cpp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "lio_types.h"
@@ -68,35 +67,6 @@ LIO_DEV void lio_top5_insert4(LioTop5& t, double b0, double b1, double b2, doubl
     double c0 = t.k0, c1 = lio_dmin(t.k1, b3), c2 = lio_dmin(t.k2, b2), c3 = lio_dmin(t.k3, b1), c4 = lio_dmin(t.k4, b0);
     LIO_CE_DESC(c0, c4); LIO_CE_DESC(c0, c2); LIO_CE_DESC(c1, c3); LIO_CE_DESC(c0, c1); LIO_CE_DESC(c2, c3);
     t.k0 = c4; t.k1 = c3; t.k2 = c2; t.k3 = c1; t.k4 = c0;
-}
-
-LIO_DEV void lio_top_insert4(LioTop5& t, double b0, double b1, double b2, double b3) { lio_top5_insert4(t, b0, b1, b2, b3); }
-
-// Top-8 (split pipeline, k_s2m_scan): the same scheme with eight keys -- sort the four new keys, element-wise
-// minimum of the upper half of the sorted top-8 with the reversed new list (the eight smallest of the twelve as a
-// bitonic sequence), 8-element bitonic merge: 5 + 12 compare-exchanges and 4 minima.
-struct LioTop8 { double k0, k1, k2, k3, k4, k5, k6, k7; };
-LIO_DEV void lio_top_insert4(LioTop8& t, double b0, double b1, double b2, double b3)
-{
-    LIO_CE_ASC(b0, b1); LIO_CE_ASC(b2, b3); LIO_CE_ASC(b0, b2); LIO_CE_ASC(b1, b3); LIO_CE_ASC(b1, b2);
-    double c0 = t.k0, c1 = t.k1, c2 = t.k2, c3 = t.k3;
-    double c4 = lio_dmin(t.k4, b3), c5 = lio_dmin(t.k5, b2), c6 = lio_dmin(t.k6, b1), c7 = lio_dmin(t.k7, b0);
-    LIO_CE_ASC(c0, c4); LIO_CE_ASC(c1, c5); LIO_CE_ASC(c2, c6); LIO_CE_ASC(c3, c7);
-    LIO_CE_ASC(c0, c2); LIO_CE_ASC(c1, c3); LIO_CE_ASC(c4, c6); LIO_CE_ASC(c5, c7);
-    LIO_CE_ASC(c0, c1); LIO_CE_ASC(c2, c3); LIO_CE_ASC(c4, c5); LIO_CE_ASC(c6, c7);
-    t.k0 = c0; t.k1 = c1; t.k2 = c2; t.k3 = c3; t.k4 = c4; t.k5 = c5; t.k6 = c6; t.k7 = c7;
-}
-
-// Eight keys in ascending order (19 compare-exchanges, the optimal 8-input network).
-LIO_DEV void lio_sort8(double& a0, double& a1, double& a2, double& a3, double& a4, double& a5, double& a6, double& a7)
-{
-    LIO_CE_ASC(a0, a1); LIO_CE_ASC(a2, a3); LIO_CE_ASC(a4, a5); LIO_CE_ASC(a6, a7);
-    LIO_CE_ASC(a0, a2); LIO_CE_ASC(a1, a3); LIO_CE_ASC(a4, a6); LIO_CE_ASC(a5, a7);
-    LIO_CE_ASC(a1, a2); LIO_CE_ASC(a5, a6); LIO_CE_ASC(a0, a4); LIO_CE_ASC(a3, a7);
-    LIO_CE_ASC(a1, a5); LIO_CE_ASC(a2, a6);
-    LIO_CE_ASC(a1, a4); LIO_CE_ASC(a3, a6);
-    LIO_CE_ASC(a2, a4); LIO_CE_ASC(a3, a5);
-    LIO_CE_ASC(a3, a4);
 }
 
 // FLANN L2_Simple: ((dx*dx) + dy*dy) + dz*dz, accumulated from 0
@@ -343,55 +313,6 @@ LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, 
 #endif
 }
 
-// the same walk keeping the eight nearest (k_s2m_scan)
-LIO_DEV void lio_knn_group8(const float4& c0, const float4& c1, const float4& c2, const float4& c3,
-                           lio_f2 qx, lio_f2 qy, lio_f2 qz, LioTop8& top)
-{
-    double k0, k1, k2, k3;
-    lio_knn_pair(c0, c1, qx, qy, qz, k0, k1);
-    lio_knn_pair(c2, c3, qx, qy, qz, k2, k3);
-    lio_top_insert4(top, k0, k1, k2, k3);
-}
-
-LIO_DEV void lio_knn_global8(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
-                            int cx, int cy, int cz, int xlo, int xhi, LioTop8& top)
-{
-    // [xlo, xhi]: x-cells that can hold a point closer than the current bound (the whole +-k range
-    // unless the previous iteration's neighbours gave a tighter one, see "neighbour cache" below)
-    const int x0 = max(max(cx - g.k, 0), xlo), x1 = min(min(cx + g.k, g.nx - 1), xhi);
-    if (x0 > x1) return;
-    const int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nx;
-    const unsigned beg = (unsigned)P.nbr_start[row + x0] & ~3u;
-    const unsigned end = (unsigned)P.nbr_start[row + x1 + 1];
-    if (beg >= end) return;
-    const lio_f2 QX = { qx, qx }, QY = { qy, qy }, QZ = { qz, qz };
-    const float4* p = P.nbr_pts + beg;                     // float4 index == record index (2 float4 per pair)
-#if LIO_PREFETCH == 2
-    // two groups in flight (the table is padded, reading up to two groups past a run is harmless)
-    float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
-    float4 n0 = p[4], n1 = p[5], n2 = p[6], n3 = p[7];
-    for (unsigned j = beg;;) {
-        float4 f0 = n0, f1 = n1, f2 = n2, f3 = n3;
-        if (j + 8 < end) { f0 = p[8]; f1 = p[9]; f2 = p[10]; f3 = p[11]; }
-        lio_knn_group8(c0, c1, c2, c3, QX, QY, QZ, top);
-        j += 4;
-        if (j >= end) break;
-        p += 4;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        n0 = f0; n1 = f1; n2 = f2; n3 = f3;
-    }
-#else
-    float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
-    for (unsigned j = beg + 4; j < end; j += 4) {
-        p += 4;
-        const float4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3];
-        lio_knn_group8(c0, c1, c2, c3, QX, QY, QZ, top);
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    }
-    lio_knn_group8(c0, c1, c2, c3, QX, QY, QZ, top);
-#endif
-}
-
 // Association of one scan point from its five nearest map points (indices into the caller's map order):
 // surfOptimization MO:1642-1683 -- plane through the neighbours, plane test, weight, coefficients -- or, for
 // the CORNER extension, the point-to-line form of upstream LIO-SAM.  Returns "accepted" (MO:1679).
@@ -435,43 +356,6 @@ LIO_DEV bool lio_assoc_point(const LioIterParams& P, const int nn[5], float qx, 
     return accept;
 }
 
-// The two halves of lio_assoc_point<false> for k_s2m_iterate_cert: the plane through the five neighbours depends on the
-// map points and their ORDER only (MO:1642-1666), not on the scan point's pose, so it can be kept from one Gauss-Newton
-// iteration to the next while the ordered neighbour tuple stays the same; the coefficients (MO:1669-1683) follow the pose.
-LIO_DEV void lio_plane_from_nn(const LioIterParams& P, const int nn[5], float& pa, float& pb, float& pc, float& pd, bool& planeValid)
-{
-    float a[5][3], m[5][3];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const float4 mp = P.map_xyz4[nn[j]];
-        m[j][0] = a[j][0] = mp.x;
-        m[j][1] = a[j][1] = mp.y;
-        m[j][2] = a[j][2] = mp.z;
-    }
-    float X0[3];
-    lio_plane_qr5x3(a, X0);                                  // MO:1648
-    pa = X0[0]; pb = X0[1]; pc = X0[2]; pd = 1;               // MO:1650-1653
-    const float ps = sqrtf(pa * pa + pb * pb + pc * pc);      // MO:1655
-    pa /= ps; pb /= ps; pc /= ps; pd /= ps;                   // MO:1656
-    planeValid = true;                                        // MO:1658-1666
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const float v = fabsf(pa * m[j][0] + pb * m[j][1] + pc * m[j][2] + pd);
-        if ((double)v > P.c.plane_tol) planeValid = false;
-    }
-}
-
-LIO_DEV bool lio_coeff_from_plane(const LioIterParams& P, float pa, float pb, float pc, float pd, float qx, float qy, float qz,
-                                  float px, float py, float pz, float& cxx, float& cyy, float& czz, float& cww)
-{
-    const float pd2 = pa * qx + pb * qy + pc * qz + pd;   // MO:1669
-    const float r2 = px * px + py * py + pz * pz;
-    // MO:1671-1672 (product, quotient and difference in double)
-    const float s = (float)(1 - P.c.weight * (double)fabsf(pd2) / (double)sqrtf(sqrtf(r2)));
-    cxx = s * pa; cyy = s * pb; czz = s * pc; cww = s * pd2;   // MO:1674-1677
-    return (double)s > P.c.min_s;                         // MO:1679
-}
-
 // (a, b) column pair of each of the 28 sums: 21 upper-triangle JtJ, 6 Jtr, N_c
 static __constant__ int c_pair_a[32] = { 0,0,0,0,0,0, 1,1,1,1,1, 2,2,2,2, 3,3,3, 4,4, 5,  0,1,2,3,4,5, 7, 0,0,0,0 };
 static __constant__ int c_pair_b[32] = { 0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5, 4,5, 5,  6,6,6,6,6,6, 7, 0,0,0,0 };
@@ -482,6 +366,10 @@ static __constant__ int c_pair_b[32] = { 0,1,2,3,4,5, 1,2,3,4,5, 2,3,4,5, 3,4,5,
 LIO_DEV void lio_arrive_and_finish(const LioIterParams& P, const LioBlockDesc& bd, LioScanState* st, int lane,
                                    double* s_sum, LioSolveWs* s_ws, long long* stamp)
 {
+    // ORDERING (release half of the arrive protocol): the caller's 28 write-through (sc1) stores of this workgroup's partial
+    // sums have left the wave's vector-memory queue -- they are complete at the agent-coherent level -- before the arrival
+    // below can be observed by another workgroup.  An agent-scope release fence would order them too, but it writes back the
+    // whole L2 of the XCD; the stores are sc1 precisely so that this counter wait is all that is needed.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int last = 0;
     if (lane == 0) {
@@ -508,7 +396,10 @@ LIO_DEV void lio_arrive_and_finish(const LioIterParams& P, const LioBlockDesc& b
         s_sum[lane] = v;
         if (P.sums_out) P.sums_out[(size_t)bd.scan * LIO_SUMS + lane] = v;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave: the sums are in LDS before anyone reads them
+    // ORDERING: the LDS writes of s_sum by lanes 0..27 are complete before lane 0 of the SAME wave reads them in lio_gn_step
+    // (acquire half: the partials themselves were read with sc1 loads issued AFTER the atomic returned -- `last` depends on
+    // its result --, so they cannot be older than the last arrival)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) P.arrive[bd.scan] = 0;                  // re-arm for the next launch
     if (!P.sums_out) lio_gn_step(st, s_sum, P.c, s_ws, P.n_active, lane);
 }

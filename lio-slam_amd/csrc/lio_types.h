@@ -71,18 +71,6 @@ struct LioBlockDesc {
     int32_t n_blk;           // chunks of this scan
 };
 
-// Split pipeline (k_s2m_cert / k_s2m_scan / k_s2m_fit): one certificate workgroup = up to
-// LIO_GROUP_BLOCKS consecutive association chunks of one scan; the group's points that still need a
-// candidate scan are listed, ordered by candidate-run length, in scan_list[list_base ...).
-#define LIO_GROUP_BLOCKS 4
-#define LIO_CACHE_K 8        // cached nearest neighbours per scan point
-struct LioGroupDesc {
-    int32_t scan;
-    int32_t first;           // first point (index within the scan)
-    int32_t n;               // points of the group (<= LIO_GROUP_BLOCKS * LIO_BLOCK)
-    int32_t list_base;       // first slot of the group in the batch SoA (= its region of scan_list)
-};
-
 // Scan-local tile grid used to re-order a scan at upload (4 m tiles by default).
 struct LioScanTiles {
     float ox, oy, oz;

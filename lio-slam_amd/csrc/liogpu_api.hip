@@ -9,224 +9,22 @@
 #include <string>
 #include <vector>
 
-#include "../../include/liogpu.h"
-#include "lio_kernels.h"
+#include "lio_handle.h"
+#include "lio_multi.h"
 #include "lio_pool.h"
-#include "lio_types.h"
 #include <mutex>
 #include <algorithm>
 
 
 static thread_local std::string g_last_error;
 
-static int lio_fail(int code, const char* what, hipError_t e = hipSuccess)
+int lio_fail(int code, const char* what, hipError_t e)
 {
     char buf[512];
     if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
     else snprintf(buf, sizeof(buf), "%s", what);
     g_last_error = buf;
     return code;
-}
-
-#define HIPCHK(expr)                                                              \
-    do {                                                                          \
-        hipError_t _e = (expr);                                                   \
-        if (_e != hipSuccess) return lio_fail(LIO_ERR_HIP, #expr, _e);            \
-    } while (0)
-
-template <typename T>
-static hipError_t lio_grow(T** p, size_t* cap, size_t need, double slack = 1.25)
-{
-    if (need <= *cap && *p) return hipSuccess;
-    if (*p) { hipError_t e = hipFree(*p); if (e != hipSuccess) return e; *p = nullptr; }
-    size_t n = (size_t)((double)need * slack) + 64;
-    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
-    if (e == hipSuccess) *cap = n;
-    else *cap = 0;
-    return e;
-}
-
-struct lio_s2m_handle {
-    lio_s2m_config cfg;
-    LioConsts c;
-    hipStream_t stream = nullptr;
-    bool own_stream = true;
-
-    // ---- resident local map (laserCloudSurfFromMapDS, MO:149) ----
-    bool has_map = false;
-    size_t n_map = 0;
-    float *d_mx = nullptr, *d_my = nullptr, *d_mz = nullptr; size_t cap_mxyz[3] = {0, 0, 0};
-    float4* d_map4 = nullptr;   size_t cap_map4 = 0;
-    float4* d_sorted = nullptr; size_t cap_sorted = 0;
-    int* d_cell_of = nullptr;   size_t cap_cell_of = 0;
-    int* d_cell_count = nullptr; size_t cap_cell_count = 0;
-    int* d_cell_start = nullptr; size_t cap_cell_start = 0;
-    int* d_tile_sums = nullptr;  size_t cap_tile_sums = 0;
-    int* d_nbr_start = nullptr;  size_t cap_nbr_start = 0;
-    float4* d_nbr_pts = nullptr; size_t cap_nbr_pts = 0;
-    int* d_nbr_slot = nullptr;   size_t cap_nbr_slot = 0;      // [n_map][(2k+1)^2] place of every replica inside its row-cell list
-    unsigned* d_bbox = nullptr;
-    unsigned char* d_stage = nullptr; size_t cap_stage = 0;
-    LioGrid grid{};
-
-    // ---- resident scan batch (laserCloudSurfLastDS, MO:138) ----
-    int n_scans = 0;
-    size_t total_pts = 0;
-    float *d_sx = nullptr, *d_sy = nullptr, *d_sz = nullptr; size_t cap_sxyz[3] = {0, 0, 0};
-    LioScanState* d_state = nullptr; size_t cap_state = 0;
-    std::vector<LioScanState> h_state;
-    std::vector<LioBlockDesc> v_blocks, v_prep;      // launch descriptors (kept alive for async H2D)
-    std::vector<LioScanTiles> v_tiles;
-    std::vector<LioBlockDesc> v_blocks_sorted;       // v_blocks re-ordered by scan position (sort_batch)
-    std::vector<int> v_order, v_first, v_first_orig;
-    bool defer_sync = false;                         // lio_s2m_register: one sync at the end of the call
-    bool async_upload = false;                       // lio_s2m_batch_upload_async: wait for the H2D copy only
-    float* d_poses = nullptr; size_t cap_poses = 0;
-    const float* reg_pose = nullptr;  // lio_s2m_register: the initial guess travels inside the state upload
-    bool pose_in_state = false;       // ... and is taken from there by the next k_s2m_init_state (which copies it to d_poses)
-    float* d_summary = nullptr; size_t cap_summary = 0;   // [n_scans][10] compact results (lio_s2m_batch_results without `results`)
-    float* h_summary = nullptr; size_t cap_h_summary = 0; // pinned
-    bool host_state_stale = false;    // h_state misses device-side updates (matP ...) since a summary-only read
-    LioBlockDesc* d_blocks = nullptr; size_t cap_blocks = 0;
-    int n_blocks = 0, ppt = 1, max_blk = 1;
-    double* d_partials = nullptr; size_t cap_partials = 0;
-    unsigned* d_arrive = nullptr; size_t cap_arrive = 0;
-    bool poses_set = false, ran = false;
-    // upload-time tile sort of the scans
-    LioScanTiles* d_tiles = nullptr; size_t cap_tiles = 0;
-    LioBlockDesc* d_prep_blocks = nullptr; size_t cap_prep_blocks = 0;
-    int* d_key_of = nullptr; size_t cap_key_of = 0;
-    int* d_key_count = nullptr; size_t cap_key_count = 0;
-    int* d_key_start = nullptr; size_t cap_key_start = 0;
-    int* d_key_tiles = nullptr; size_t cap_key_tiles = 0;
-    int* d_tmp_idx = nullptr; size_t cap_tmp_idx = 0;
-    int* d_perm = nullptr; size_t cap_perm = 0;
-    float* d_block_box = nullptr; size_t cap_block_box = 0;   // map sharding: per-workgroup bounding boxes (cull)
-    bool has_block_box = false;
-    unsigned char* d_blk_skip = nullptr; size_t cap_blk_skip = 0;
-    int* d_big_list = nullptr; size_t cap_big_list = 0;   // tiles with more than LIO_TILE_CAP points (+ their count in the last slot)
-    unsigned* d_scan_bbox = nullptr; size_t cap_scan_bbox = 0;   // [n_scans][6] ordered-uint bounding boxes
-    unsigned* h_scan_bbox = nullptr; size_t cap_h_scan_bbox = 0; // pinned mirror
-    bool sorted = false;
-    const unsigned char* last_stage = nullptr;   // the records of the resident batch as uploaded (d_stage, or the caller's device buffer)
-    size_t last_stride = 0, last_xyz_off = 0;
-    size_t xyz_off = 0;                  // byte offset of x inside a record for the NEXT upload (lio_s2m_register_pc2)
-    lio_s2m_handle* map_src = nullptr;   // lio_s2m_share_map: the handle whose resident map this one searches
-    unsigned long long map_epoch = 0;    // bumped by every set_map
-    float* d_nn_cache = nullptr; size_t cap_nn_cache = 0;   // [total_pts] squared 5th-neighbour distance of the previous GN iteration
-    long long* d_stamps = nullptr; size_t cap_stamps = 0;
-    // split pipeline (cfg.pipeline): neighbour cache + per-iteration scan work list
-    bool split = false;               // the resident batch runs k_s2m_cert / _scan / _fit instead of k_s2m_iterate
-    bool certk = false;               // the resident batch runs k_s2m_iterate_cert (cfg.pipeline = 3)
-    bool reusek = false;              // the resident batch runs k_s2m_iterate_reuse (cfg.pipeline = 5: kept planes)
-    // one-launch loop (cfg.pipeline = 4, k_s2m_persist): per-scan generation numbers
-    unsigned* d_gen = nullptr; size_t cap_gen = 0;     // [2][cap_gen / 2]: generation numbers, then the speculation states
-    double* d_spec_sums = nullptr; size_t cap_spec_sums = 0;   // sums of the first solve of every scan (roll-back of the speculation)
-    unsigned gen_epoch = 0;           // grows by 128 per run: generation numbers are never cleared
-    int n_cu = 0;                     // compute units of the device: every workgroup of a one-launch loop must be resident
-    bool run_persist = false;
-    bool soa_valid = true;            // d_sx/d_sy/d_sz hold the resident batch (false: a one-launch batch still only staged as records)
-    bool cache_dirty = true;          // map or batch changed: the neighbour cache must be dropped before the next run
-    std::vector<LioGroupDesc> v_groups;
-    LioGroupDesc* d_groups = nullptr; size_t cap_groups = 0;
-    int* d_cache_idx = nullptr; size_t cap_cache_idx = 0;
-    float4* d_cache_q = nullptr; size_t cap_cache_q = 0;
-    int* d_pt_flag = nullptr; size_t cap_pt_flag = 0;
-    float* d_scan_bound2 = nullptr; size_t cap_scan_bound2 = 0;
-    int* d_scan_list = nullptr; size_t cap_scan_list = 0;
-    int* d_scan_cnt = nullptr; size_t cap_scan_cnt = 0;
-    float4* d_plane = nullptr; size_t cap_plane = 0;
-    int* d_plane_state = nullptr; size_t cap_plane_state = 0;
-    int* d_split_stats = nullptr; size_t cap_split_stats = 0;      // [32][n_groups]
-    // hipGraph-captured chunk of GN iterations (cfg.use_graph)
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    bool graph_dirty = true;
-    int graph_chunk = 0, graph_blocks = 0, graph_ppt = 0;
-    LioIterParams graph_params;       // arguments the cached graph was captured with
-    int units_this_run = 0, unit_iters = 1;
-
-    // correspondence record (debug / parity)
-    unsigned char* d_rec_flag = nullptr; size_t cap_rec_flag = 0;
-    float* d_rec_coeff = nullptr; size_t cap_rec_coeff = 0;
-    int* d_rec_nn = nullptr; size_t cap_rec_nn = 0;
-
-    // in-library multi-GPU mode (cfg.n_devices > 1): this handle is only a front; see struct LioMulti
-    struct LioMulti* multi = nullptr;
-
-    // resumable launch loop (lio_s2m_batch_run / lio_run_continue)
-    bool run_pending = false, run_graph = false, run_has_c = false;
-    int run_next = 0, run_units = 0, run_look = 0;
-    LioIterParams run_P, run_Pc;
-
-    // sharding
-    LioShard shard{};
-    float gorigin[3] = {0, 0, 0};
-    int gdims[3] = {0, 0, 0};
-    bool has_global = false;
-    int block_rank = 0, block_world = 1;   // scan-range sharding
-    int plan_ranks = 0, plan_rank = 0, plan_halo = 1, plan_bounds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // lio_s2m_set_shard_plan
-
-    // EXTENSION: point-to-line residuals.  `corner` is a child handle that owns the corner
-    // map (its grid and neighbourhood rows) and the batch of edge points; its association launch writes
-    // into THIS handle's per-scan partial sums and state.
-    lio_s2m_handle* corner = nullptr;
-    bool corner_active = false;       // a corner batch matching the current surf batch is resident
-    LioIterParams graph_params_c;
-    int graph_blocks_c = 0;
-
-    // profiling
-    hipEvent_t ev_beg[LIO_MAX_ITERS] = {}, ev_end[LIO_MAX_ITERS] = {}, ev_chk[LIO_MAX_ITERS] = {};
-    hipEvent_t ev_map[2] = {};
-    hipEvent_t ev_mapl[2] = {};        // asynchronous map installation (lio_s2m_set_map_device_bbox): build time resolved on demand; [1] = "map ready"
-    bool map_timing_pending = false;
-    int* h_active = nullptr;          // pinned: active-scan count after each launch
-    bool ev_ok = false;
-    lio_s2m_profile prof{};
-    int launches_this_run = 0;
-    int* d_active = nullptr;
-};
-
-// ---------------------------------------------------------------- in-library multi-GPU
-// cfg.n_devices > 1: the handle returned by lio_s2m_create is a front for one child handle per entry of
-// cfg.device_ids.  lio_s2m_set_map cuts the map into slabs of 1.001 m cells along its longest axis, balanced by point
-// count; every child holds its slab plus a one-cell halo and processes the scan points whose transformed position falls
-// into a cell it owns (the exact per-point test and the workgroup cull of k_shard_cull).  One host thread drives all
-// devices through their streams; per Gauss-Newton iteration the per-scan sums (32 doubles each) of every child are
-// copied to pinned host memory, added in DEVICE ORDER (bitwise reproducible) and handed back, and every child runs
-// the identical solve -- the join the reference gets from its OpenMP barrier at MO:1622-1686.  The same device may
-// be listed more than once (that is how the mode is tested on a one-GPU box).
-#define LIO_MULTI_HALO 16      // cells of map a device holds beyond its slab: workgroups up to ~30 m long stay whole (k_shard_cull)
-struct LioMulti {
-    std::vector<lio_s2m_handle*> dev;
-    std::vector<double*> d_part, d_tot, h_part;      // per child: device partial / total sums, pinned host partial sums
-    double* h_tot = nullptr;                          // pinned: the sums over all children
-    size_t cap_scans = 0;
-    std::vector<std::vector<int>> shard_idx;          // per child: caller's map index of every point of its shard
-    std::vector<unsigned char> gather;                // host staging of one shard's records
-    int n_scans = 0;
-};
-
-static int lio_multi_reserve(lio_s2m_handle* h, size_t n_scans)
-{
-    LioMulti* m = h->multi;
-    if (n_scans <= m->cap_scans) return LIO_OK;
-    const size_t cap = n_scans + n_scans / 4 + 16, bytes = cap * LIO_SUMS * sizeof(double);
-    for (size_t c = 0; c < m->dev.size(); ++c) {
-        HIPCHK(hipSetDevice(m->dev[c]->cfg.device_id));
-        if (m->d_part[c]) HIPCHK(hipFree(m->d_part[c]));
-        if (m->d_tot[c]) HIPCHK(hipFree(m->d_tot[c]));
-        if (m->h_part[c]) HIPCHK(hipHostFree(m->h_part[c]));
-        m->d_part[c] = m->d_tot[c] = m->h_part[c] = nullptr;
-        HIPCHK(hipMalloc((void**)&m->d_part[c], bytes));
-        HIPCHK(hipMalloc((void**)&m->d_tot[c], bytes));
-        HIPCHK(hipHostMalloc((void**)&m->h_part[c], bytes, hipHostMallocPortable));
-    }
-    if (m->h_tot) HIPCHK(hipHostFree(m->h_tot));
-    m->h_tot = nullptr;
-    HIPCHK(hipHostMalloc((void**)&m->h_tot, bytes, hipHostMallocPortable));
-    m->cap_scans = cap;
-    return LIO_OK;
 }
 
 extern "C" int lio_version(void) { return LIO_VERSION; }
@@ -309,36 +107,16 @@ extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
     if (cfg->k != 5) return lio_fail(LIO_ERR_ARG, "only k = 5 is supported (MO:1631)");
     if (cfg->max_iters < 1 || cfg->max_iters > LIO_MAX_ITERS) return lio_fail(LIO_ERR_ARG, "max_iters out of range");
     if (!(cfg->max_sq_dist > 0.0f)) return lio_fail(LIO_ERR_ARG, "max_sq_dist must be positive");
+    if (cfg->pipeline != 0 && cfg->pipeline != 1 && cfg->pipeline != 4)
+        return lio_fail(LIO_ERR_ARG, "cfg.pipeline must be 0 (auto), 1 (one launch per iteration) or 4 (one-launch loop)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return lio_fail(LIO_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return lio_fail(LIO_ERR_ARG, "device_id out of range");
-    if (cfg->n_devices > 1) {
-        // in-library multi-GPU: a front handle + one child per listed device (see struct LioMulti)
-        if (cfg->n_devices > 8) return lio_fail(LIO_ERR_ARG, "n_devices must be <= 8");
-        for (int i = 0; i < cfg->n_devices; ++i)
-            if (cfg->device_ids[i] < 0 || cfg->device_ids[i] >= ndev) return lio_fail(LIO_ERR_ARG, "device_ids entry out of range");
-        if (cfg->use_lds || cfg->pipeline == 2 || cfg->kernel_variant > 1)
-            return lio_fail(LIO_ERR_ARG, "the multi-device mode runs the default kernel only");
-        lio_s2m_handle* f = new lio_s2m_handle();
-        f->cfg = *cfg;
-        lio_fill_consts(f);
-        f->shard.axis = -1;
-        f->multi = new LioMulti();
-        for (int i = 0; i < cfg->n_devices; ++i) {
-            lio_s2m_config cc = *cfg;
-            cc.n_devices = 1;
-            cc.device_id = cfg->device_ids[i];
-            cc.use_graph = 0;                        // the loop is driven iteration by iteration (one exchange each)
-            lio_s2m_handle* ch = nullptr;
-            const int rc = lio_s2m_create(&cc, &ch);
-            if (rc != LIO_OK) { lio_s2m_destroy(f); return rc; }
-            f->multi->dev.push_back(ch);
-            f->multi->d_part.push_back(nullptr); f->multi->d_tot.push_back(nullptr); f->multi->h_part.push_back(nullptr);
-        }
-        f->multi->shard_idx.resize((size_t)cfg->n_devices);
-        *out = f;
-        return LIO_OK;
+    if (cfg->n_devices > 1) {                           // in-library multi-GPU: a front handle + one child per listed device (lio_multi.hip)
+        const int rc = lio_multi_create(cfg, out);
+        if (rc == LIO_OK) lio_fill_consts(*out);
+        return rc;
     }
     HIPCHK(hipSetDevice(cfg->device_id));
     lio_s2m_handle* h = new lio_s2m_handle();
@@ -358,31 +136,17 @@ extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
 extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
 {
     if (!h) return;
-    if (h->multi) {
-        LioMulti* m = h->multi;
-        for (size_t c = 0; c < m->dev.size(); ++c) {
-            (void)hipSetDevice(m->dev[c]->cfg.device_id);
-            (void)hipStreamSynchronize(m->dev[c]->stream);
-            if (m->d_part[c]) (void)hipFree(m->d_part[c]);
-            if (m->d_tot[c]) (void)hipFree(m->d_tot[c]);
-            if (m->h_part[c]) (void)hipHostFree(m->h_part[c]);
-            lio_s2m_destroy(m->dev[c]);
-        }
-        if (m->h_tot) (void)hipHostFree(m->h_tot);
-        delete m;
-        delete h;
-        return;
-    }
+    if (h->multi) { lio_multi_destroy(h); return; }
     (void)hipSetDevice(h->cfg.device_id);
     (void)hipStreamSynchronize(h->stream);
     if (h->corner) { lio_s2m_destroy(h->corner); h->corner = nullptr; }
+    if (h->raw_ws) { lio_raw_ws_free(h->raw_ws); h->raw_ws = nullptr; }
     void* ptrs[] = { h->d_mx, h->d_my, h->d_mz, h->d_map4, h->d_sorted, h->d_cell_of, h->d_cell_count,
                      h->d_cell_start, h->d_tile_sums, h->d_bbox, h->d_stage, h->d_sx, h->d_sy, h->d_sz,
                      h->d_state, h->d_poses, h->d_blocks, h->d_partials, h->d_arrive, h->d_rec_flag,
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
                      h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
-                     h->d_nn_cache, h->d_summary, h->d_groups, h->d_cache_idx, h->d_cache_q, h->d_pt_flag,
-                     h->d_scan_bound2, h->d_scan_list, h->d_scan_cnt, h->d_split_stats, h->d_big_list, h->d_scan_bbox, h->d_block_box, h->d_blk_skip, h->d_plane, h->d_plane_state, h->d_gen, h->d_spec_sums, h->d_nbr_slot };
+                     h->d_nn_cache, h->d_summary, h->d_big_list, h->d_scan_bbox, h->d_block_box, h->d_blk_skip, h->d_gen, h->d_spec_sums, h->d_nbr_slot };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < LIO_MAX_ITERS; ++i) {               // (a handle whose creation failed half-way holds nulls)
         if (h->ev_beg[i]) (void)hipEventDestroy(h->ev_beg[i]);
@@ -515,79 +279,7 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
     h->n_map = n;
     h->has_map = true;
     h->graph_dirty = true;
-    h->cache_dirty = true;            // cached neighbour indices refer to the previous map
     h->map_epoch++;
-    return LIO_OK;
-}
-
-// Multi-device set_map: slab plan on the host (the same arithmetic as lio-slam_amd/multigpu.py plan_shards and as the
-// device-side owner test), then every child receives its slab + one-cell halo in the caller's record layout.
-static int lio_multi_set_map(lio_s2m_handle* h, const void* pts, size_t n, size_t stride)
-{
-    LioMulti* m = h->multi;
-    const int world = (int)m->dev.size();
-    const unsigned char* src = (const unsigned char*)pts;
-    const float cell = h->cfg.cell_size > 0.0f ? h->cfg.cell_size : sqrtf(h->cfg.max_sq_dist) * 1.001f;
-    const float inv_cell = 1.0f / cell;
-    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
-    for (size_t i = 0; i < n; ++i) {
-        const float* p = (const float*)(src + i * stride);
-        for (int a = 0; a < 3; ++a)
-            if (fabsf(p[a]) <= 1.0e15f) { if (p[a] < mn[a]) mn[a] = p[a]; if (p[a] > mx[a]) mx[a] = p[a]; }
-    }
-    float origin[3];
-    int32_t dims[3];
-    int axis = 0;
-    for (int a = 0; a < 3; ++a) {
-        if (!(mn[a] <= mx[a])) { mn[a] = 0.0f; mx[a] = 0.0f; }
-        origin[a] = mn[a] - 0.5f * cell;
-        dims[a] = (int32_t)floor(((double)mx[a] - origin[a]) * inv_cell) + 2;
-        if (dims[a] > dims[axis]) axis = a;
-    }
-    auto cell_of = [&](float v) {                          // lio_cell_coord(), clamped to the grid
-        float c = floorf((v - origin[axis]) * inv_cell);
-        c = fminf(fmaxf(c, -4.0f), (float)(dims[axis] + 3));
-        int ci = (int)c;
-        return ci < 0 ? 0 : (ci > dims[axis] - 1 ? dims[axis] - 1 : ci);
-    };
-    std::vector<long long> cum((size_t)dims[axis], 0);
-    std::vector<int> pc(n);
-    for (size_t i = 0; i < n; ++i) {
-        const float* p = (const float*)(src + i * stride);
-        const bool ok = fabsf(p[0]) <= 1.0e15f && fabsf(p[1]) <= 1.0e15f && fabsf(p[2]) <= 1.0e15f;
-        pc[i] = ok ? cell_of(p[axis]) : -1000;             // non-finite points belong to no slab (they are no neighbour of anything)
-        if (ok) cum[(size_t)pc[i]]++;
-    }
-    for (size_t c = 1; c < cum.size(); ++c) cum[c] += cum[c - 1];
-    const long long total = cum.empty() ? 0 : cum.back();
-    std::vector<int> bounds((size_t)world + 1, 0);
-    bounds[(size_t)world] = dims[axis];
-    for (int r = 1; r < world; ++r) {
-        const double want = (double)total * r / world;
-        size_t lo = 0;
-        while (lo < cum.size() && (double)cum[lo] < want) ++lo;   // first cell whose cumulative count reaches the share
-        bounds[(size_t)r] = (int)lo + 1;
-        if (bounds[(size_t)r] > dims[axis]) bounds[(size_t)r] = dims[axis];
-        if (bounds[(size_t)r] < bounds[(size_t)r - 1]) bounds[(size_t)r] = bounds[(size_t)r - 1];
-    }
-    for (int r = 0; r < world; ++r) {
-        const int lo = bounds[(size_t)r], hi = bounds[(size_t)r + 1];
-        std::vector<int>& idx = m->shard_idx[(size_t)r];
-        idx.clear();
-        for (size_t i = 0; i < n; ++i)
-            if (pc[i] >= lo - LIO_MULTI_HALO && pc[i] < hi + LIO_MULTI_HALO) idx.push_back((int)i);
-        m->gather.resize((idx.size() ? idx.size() : 1) * stride);
-        for (size_t k = 0; k < idx.size(); ++k) memcpy(m->gather.data() + k * stride, src + (size_t)idx[k] * stride, stride);
-        lio_s2m_handle* ch = m->dev[(size_t)r];
-        int rc = lio_s2m_set_map(ch, m->gather.data(), idx.size(), stride);
-        if (rc == LIO_OK) rc = lio_s2m_set_global_grid(ch, origin, dims);
-        if (rc == LIO_OK) rc = lio_s2m_set_shard_plan(ch, axis, world, r, bounds.data(), LIO_MULTI_HALO);
-        if (rc != LIO_OK) return rc;
-    }
-    h->has_map = true;
-    h->n_map = n;
-    h->prof = m->dev[0]->prof;
-    h->prof.n_map = (int64_t)n;
     return LIO_OK;
 }
 
@@ -678,7 +370,6 @@ extern "C" int lio_s2m_share_map(lio_s2m_handle* h, lio_s2m_handle* map_owner)
         return lio_fail(LIO_ERR_ARG, "the map owner must hold its own map on the same device");
     h->map_src = map_owner;
     h->map_epoch = map_owner ? map_owner->map_epoch : 0;
-    h->cache_dirty = true;
     h->graph_dirty = true;
     return LIO_OK;
 }
@@ -756,36 +447,6 @@ extern "C" int lio_s2m_set_shard_plan(lio_s2m_handle* h, int32_t axis, int32_t n
     return LIO_OK;
 }
 
-// Certificate workgroups of the split pipeline: up to LIO_GROUP_BLOCKS consecutive association chunks of
-// one scan, in the order of the (possibly re-ordered) workgroup list.
-static int lio_build_groups(lio_s2m_handle* h, const std::vector<LioBlockDesc>& blocks)
-{
-    std::vector<LioGroupDesc>& gr = h->v_groups;
-    gr.clear();
-    for (size_t i = 0; i < blocks.size();) {
-        const LioBlockDesc& b0 = blocks[i];
-        const LioScanState& st = h->h_state[b0.scan];
-        size_t j = i + 1;
-        while (j < blocks.size() && j - i < LIO_GROUP_BLOCKS && blocks[j].scan == b0.scan &&
-               blocks[j].first == blocks[j - 1].first + LIO_BLOCK)
-            ++j;
-        const int last = blocks[j - 1].first + LIO_BLOCK;
-        LioGroupDesc g;
-        g.scan = b0.scan;
-        g.first = b0.first;
-        g.n = (last < st.n_pts ? last : st.n_pts) - b0.first;
-        g.list_base = st.offset + b0.first;
-        gr.push_back(g);
-        i = j;
-    }
-    HIPCHK(lio_grow(&h->d_groups, &h->cap_groups, gr.size() ? gr.size() : 1));
-    HIPCHK(lio_grow(&h->d_scan_cnt, &h->cap_scan_cnt, gr.size() ? gr.size() : 1));
-    if (h->cfg.profile) HIPCHK(lio_grow(&h->d_split_stats, &h->cap_split_stats, (gr.size() ? gr.size() : 1) * LIO_MAX_ITERS));
-    if (!gr.empty())
-        HIPCHK(hipMemcpyAsync(h->d_groups, gr.data(), gr.size() * sizeof(LioGroupDesc), hipMemcpyHostToDevice, h->stream));
-    return LIO_OK;
-}
-
 // ------------------------------------------------------------------- batch
 // The whole Gauss-Newton loop as one launch (k_s2m_persist, lio_persist.hip): possible when every workgroup of the batch is
 // resident at once and the batch uses nothing but the default surf association; measured faster than the launch loop
@@ -799,8 +460,28 @@ static bool lio_persist_eligible(const lio_s2m_handle* h)
     int limit = 0;
     if (h->cfg.pipeline == 4) limit = h->n_cu;
     else if (h->cfg.pipeline == 0 && !h->cfg.use_graph && h->cfg.profile != 2) limit = h->n_cu / 4;
-    return limit > 0 && !h->split && !h->certk && !h->reusek && !h->cfg.use_lds && h->ppt == 1 && h->shard.axis < 0 &&
+    return limit > 0 && !h->no_persist && !h->cfg.use_lds && h->ppt == 1 && h->shard.axis < 0 &&
            h->block_world == 1 && h->n_blocks > 0 && h->n_blocks + h->n_scans <= limit;      // (+ one helper workgroup per scan)
+}
+
+// Polls before a workgroup of the one-launch loop stops waiting for its scan's solve.  A poll is a short sleep plus one
+// L2-bypassing load (~1-2 us): the default of 4096 bounds a stalled launch to a few milliseconds, after which the host re-runs
+// the registration through the launch loop (lio_s2m_batch_results).  A healthy solve is answered within ~50 us.
+static unsigned lio_persist_spin_max(const lio_s2m_handle* h)
+{
+    if (h->persist_spin_max) return h->persist_spin_max;
+    static const unsigned env = [] { const char* e = getenv("LIO_PERSIST_SPIN_MAX"); const long v = e ? atol(e) : 0; return v > 0 ? (unsigned)v : 4096u; }();
+    return env;
+}
+
+// Test hook: bound of the one-launch loop's barrier polls for this handle (0 = default) and the index of an association
+// workgroup that never arrives (-1 = none), which forces the time-out and with it the fall-back to the launch loop.
+extern "C" int lio_s2m_debug_persist_spin(lio_s2m_handle* h, int32_t spin_max, int32_t withhold_wg)
+{
+    if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
+    h->persist_spin_max = spin_max > 0 ? (unsigned)spin_max : 0u;
+    h->persist_withhold = withhold_wg;
+    return LIO_OK;
 }
 
 // The SoA copy of the resident batch, for the paths that read it, if the upload skipped it.
@@ -819,21 +500,7 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     if (!h || !scans || !n_pts) return lio_fail(LIO_ERR_ARG, "null argument");
     if (n_scans < 1) return lio_fail(LIO_ERR_ARG, "n_scans must be >= 1");
     if (stride < 12 || (stride & 3)) return lio_fail(LIO_ERR_ARG, "stride_bytes must be >= 12 and a multiple of 4");
-    if (h->multi) {
-        // every device holds every scan: which device owns a point follows the pose, iteration by iteration
-        for (lio_s2m_handle* ch : h->multi->dev) {
-            ch->defer_sync = true;                       // all copies in flight together, one wait per device below
-            ch->xyz_off = h->xyz_off;
-            const int rc = lio_s2m_batch_upload(ch, n_scans, scans, n_pts, stride);
-            ch->defer_sync = false;
-            if (rc != LIO_OK) return rc;
-        }
-        h->xyz_off = 0;
-        for (lio_s2m_handle* ch : h->multi->dev) { const int rc = lio_s2m_batch_sync(ch); if (rc != LIO_OK) return rc; }
-        h->multi->n_scans = n_scans;
-        h->n_scans = n_scans;
-        return lio_multi_reserve(h, (size_t)n_scans);
-    }
+    if (h->multi) return lio_multi_upload(h, n_scans, scans, n_pts, stride);
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     size_t total = 0, max_n = 0;
@@ -873,31 +540,6 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     int ppt = h->cfg.kernel_variant;
     if (ppt != 1 && ppt != 2 && ppt != 4) ppt = 1;       // auto: one point per thread measured fastest at every batch size tried
     h->ppt = ppt;
-    // split pipeline (opt-in, cfg.pipeline = 2): neighbour certificate + candidate scan + fit as three launches
-    // (lio_split.hip).  Bit-identical, and measured SLOWER than the fused launch on an MI355X (DESIGN.md section 6:
-    // 2.2 ms vs 1.5 ms of kernel time per 512-scan step), so auto (0) means fused.
-    h->split = ppt == 1 && !h->cfg.use_lds && h->cfg.profile != 2 && h->cfg.pipeline == 2;
-    // cfg.pipeline = 3: the fused launch with the certificate inside (k_s2m_iterate_cert, lio_cert.hip)
-    h->certk = ppt == 1 && !h->cfg.use_lds && h->cfg.profile != 2 && h->cfg.pipeline == 3;
-    // cfg.pipeline = 5: the fused launch that keeps a point's plane while its ordered neighbour tuple stays the same (lio_reuse.hip)
-    h->reusek = ppt == 1 && !h->cfg.use_lds && h->cfg.profile != 2 && h->cfg.pipeline == 5;
-    if (h->reusek) {
-        HIPCHK(lio_grow(&h->d_cache_idx, &h->cap_cache_idx, tt * LIO_CACHE_K));
-        HIPCHK(lio_grow(&h->d_plane, &h->cap_plane, tt));
-        HIPCHK(lio_grow(&h->d_plane_state, &h->cap_plane_state, tt));
-    }
-    if (h->split || h->certk) {
-        HIPCHK(lio_grow(&h->d_cache_idx, &h->cap_cache_idx, tt * LIO_CACHE_K));
-        HIPCHK(lio_grow(&h->d_cache_q, &h->cap_cache_q, tt));
-        HIPCHK(lio_grow(&h->d_pt_flag, &h->cap_pt_flag, tt));
-        HIPCHK(lio_grow(&h->d_scan_bound2, &h->cap_scan_bound2, tt));
-        HIPCHK(lio_grow(&h->d_scan_list, &h->cap_scan_list, tt));
-        if (h->certk) {
-            HIPCHK(lio_grow(&h->d_plane, &h->cap_plane, tt));
-            HIPCHK(lio_grow(&h->d_plane_state, &h->cap_plane_state, tt));
-        }
-    }
-    h->cache_dirty = true;
     const size_t per_blk = (size_t)LIO_BLOCK * ppt;
     std::vector<LioBlockDesc>& blocks = h->v_blocks;
     blocks.clear();
@@ -964,6 +606,8 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
         HIPCHK(hipEventSynchronize(h->ev_map[0]));
     }
     h->last_stage = stage; h->last_stride = stride; h->last_xyz_off = h->xyz_off;
+    h->last_int_off = h->int_off != -2 ? h->int_off : ((h->xyz_off == 0 && stride >= 20) ? 16 : -1);
+    h->int_off = -2;
     stage += h->xyz_off;                                 // (x, y, z are read at +0, +4, +8 from here; xyz_off + 12 <= stride)
     h->xyz_off = 0;
     h->v_first_orig.assign((size_t)n_scans + 1, 0);
@@ -990,8 +634,6 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     if (!blocks.empty())
         HIPCHK(hipMemcpyAsync(h->d_blocks, blocks.data(), blocks.size() * sizeof(LioBlockDesc),
                               hipMemcpyHostToDevice, h->stream));
-    if (h->split) { const int rcg = lio_build_groups(h, blocks); if (rcg != LIO_OK) return rcg; }
-    else h->v_groups.clear();
     HIPCHK(hipMemcpyAsync(h->d_state, h->h_state.data(), (size_t)n_scans * sizeof(LioScanState),
                           hipMemcpyHostToDevice, h->stream));
     std::vector<LioScanTiles>& tiles = h->v_tiles;
@@ -1186,11 +828,7 @@ extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
 {
     if (!h || !poses) return lio_fail(LIO_ERR_ARG, "null argument");
     if (h->n_scans < 1) return lio_fail(LIO_ERR_ARG, "no batch uploaded");
-    if (h->multi) {
-        for (lio_s2m_handle* ch : h->multi->dev) { const int rc = lio_s2m_batch_set_poses(ch, poses); if (rc != LIO_OK) return rc; }
-        h->poses_set = true;
-        return LIO_OK;
-    }
+    if (h->multi) return lio_multi_set_poses(h, poses);
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     h->run_pending = false;            // (a run whose results were never fetched is abandoned)
@@ -1223,7 +861,6 @@ extern "C" int lio_s2m_batch_set_poses(lio_s2m_handle* h, const float* poses)
             for (int i = h->v_first_orig[s]; i < h->v_first_orig[s + 1]; ++i) sorted.push_back(h->v_blocks[i]);
         }
         HIPCHK(hipMemcpyAsync(h->d_blocks, sorted.data(), sorted.size() * sizeof(LioBlockDesc), hipMemcpyHostToDevice, h->stream));
-        if (h->split) { const int rcg = lio_build_groups(h, sorted); if (rcg != LIO_OK) return rcg; }
     }
     if (!h->defer_sync) HIPCHK(hipStreamSynchronize(h->stream));
     h->poses_set = true;
@@ -1234,10 +871,7 @@ extern "C" int lio_s2m_set_degeneracy(lio_s2m_handle* h, int32_t scan, const flo
 {
     if (!h || !matP) return lio_fail(LIO_ERR_ARG, "null argument");
     if (scan < 0 || scan >= h->n_scans) return lio_fail(LIO_ERR_ARG, "scan slot out of range");
-    if (h->multi) {
-        for (lio_s2m_handle* ch : h->multi->dev) { const int rc = lio_s2m_set_degeneracy(ch, scan, matP, is_degenerate); if (rc != LIO_OK) return rc; }
-        return LIO_OK;
-    }
+    if (h->multi) return lio_multi_set_degeneracy(h, scan, matP, is_degenerate);
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     LioScanState& st = h->h_state[scan];
@@ -1284,25 +918,6 @@ static void lio_fill_params(lio_s2m_handle* h, LioIterParams& P, double* sums_ou
     if (P.blk_skip) P.xcd_remap = 0;
 }
 
-static void lio_fill_split(lio_s2m_handle* h, const LioIterParams& P, LioSplitParams& S)
-{
-    memset(&S, 0, sizeof(S));
-    S.it = P;
-    S.groups = h->d_groups;
-    S.n_groups = (int)h->v_groups.size();
-    S.cache_idx = h->d_cache_idx;
-    S.cache_q = h->d_cache_q;
-    S.pt_flag = h->d_pt_flag;
-    S.scan_bound2 = h->d_scan_bound2;
-    S.scan_list = h->d_scan_list;
-    S.scan_cnt = h->d_scan_cnt;
-    S.plane = h->d_plane;
-    S.plane_state = h->d_plane_state;
-    S.stats = h->cfg.profile ? h->d_split_stats : nullptr;
-    const char* sm = getenv("LIO_SPLIT_SORT");
-    S.sort_mode = sm ? atoi(sm) : 0;      // measured: 0 (as they come) 246 us, 1 (by run length) 302 us, 2 (per chunk) 249 us for the first scan launch
-}
-
 // Arguments of the corner launch: the child's map, grid, edge points and workgroup list; everything
 // that is per scan (state, partial sums, arrival counters, active count) is the parent's.
 static void lio_fill_params_corner(lio_s2m_handle* h, LioIterParams& Pc, double* sums_out)
@@ -1323,22 +938,7 @@ static void lio_fill_params_corner(lio_s2m_handle* h, LioIterParams& Pc, double*
 static void lio_launch_gn(lio_s2m_handle* h, const LioIterParams& P, const LioIterParams* Pc)
 {
     if (Pc) lio_launch_iterate(*Pc, h->corner->n_blocks, 1, false, h->stream, true);
-    if (h->split) {
-        LioSplitParams S;
-        lio_fill_split(h, P, S);
-        lio_launch_split_iteration(S, h->n_blocks, h->stream);
-    } else if (h->certk) {
-        LioSplitParams S;
-        lio_fill_split(h, P, S);
-        S.it.d5_cache = nullptr;
-        lio_launch_iterate_cert(S, h->n_blocks, h->stream);
-    } else if (h->reusek) {
-        LioSplitParams S;
-        lio_fill_split(h, P, S);
-        lio_launch_iterate_reuse(S, h->n_blocks, h->stream);
-    } else {
-        lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
-    }
+    lio_launch_iterate(P, h->n_blocks, h->ppt, h->cfg.use_lds != 0, h->stream);
 }
 
 extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
@@ -1351,24 +951,11 @@ extern "C" int lio_s2m_batch_begin(lio_s2m_handle* h)
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     if (h->map_src && h->map_epoch != h->map_src->map_epoch) {      // the shared map was replaced since the last run
         h->map_epoch = h->map_src->map_epoch;
-        h->cache_dirty = true;
         h->graph_dirty = true;
         HIPCHK(hipStreamWaitEvent(h->stream, h->map_src->ev_mapl[1], 0));   // (its build may still be in flight on the owner's stream)
     }
     lio_launch_init_state(h->d_state, h->n_scans, h->d_poses, h->pose_in_state, h->c, h->d_active, h->stream);
     h->pose_in_state = false;          // (d_poses holds the guess from now on)
-    if (h->split && h->cfg.profile && h->d_split_stats)
-        HIPCHK(hipMemsetAsync(h->d_split_stats, 0, h->v_groups.size() * LIO_MAX_ITERS * sizeof(int), h->stream));
-    if (h->reusek && h->cache_dirty) {
-        HIPCHK(hipMemsetAsync(h->d_plane_state, 0, (h->total_pts ? h->total_pts : 1) * sizeof(int), h->stream));
-        h->cache_dirty = false;
-    }
-    if ((h->split || h->certk) && h->cache_dirty) {
-        // 0xff bytes = NaN in the bound word: "no cache" (the `>= 0` test fails)
-        HIPCHK(hipMemsetAsync(h->d_cache_q, 0xff, (h->total_pts ? h->total_pts : 1) * sizeof(float4), h->stream));
-        if (h->certk) HIPCHK(hipMemsetAsync(h->d_plane_state, 0, (h->total_pts ? h->total_pts : 1) * sizeof(int), h->stream));
-        h->cache_dirty = false;
-    }
     // search-bound cache: iteration 0 never reads it and rewrites the entry of every point it processes; entries
     // of points it does not process (owned by another rank) could date from an earlier run -> drop them
     // (0xff bytes = NaN, which fails the `>= 0` validity test like -1 does)
@@ -1436,7 +1023,7 @@ static int lio_run_continue(lio_s2m_handle* h, bool blocking)
         if (h->run_persist) {
             lio_launch_persist(h->run_P, h->n_blocks, h->d_gen, h->gen_epoch, h->soa_valid ? nullptr : h->last_stage + h->last_xyz_off,
                                h->last_stride, h->n_scans, getenv("LIO_NO_SPEC") ? nullptr : h->d_gen + h->n_scans, h->d_spec_sums, h->d_poses,
-                               h->stream);
+                               lio_persist_spin_max(h), h->persist_withhold, h->stream);
         } else if (h->run_graph) HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
         else lio_launch_gn(h, h->run_P, Pc);
         if (prof) HIPCHK(hipEventRecord(h->ev_end[u], h->stream));
@@ -1448,45 +1035,6 @@ static int lio_run_continue(lio_s2m_handle* h, bool blocking)
     }
     h->run_pending = false;
     HIPCHK(hipGetLastError());
-    return LIO_OK;
-}
-
-// Multi-device Gauss-Newton loop (blocking): association on every device, exchange of the per-scan sums through pinned
-// host memory (added in device order), the identical solve on every device; MO:1848-1859 with the join of MO:1622-1686.
-static int lio_multi_run(lio_s2m_handle* h)
-{
-    LioMulti* m = h->multi;
-    if (!h->has_map) return lio_fail(LIO_ERR_NO_MAP, "set_map has not been called");
-    if (m->n_scans < 1 || !h->poses_set) return lio_fail(LIO_ERR_ARG, "batch_upload and batch_set_poses first");
-    const size_t n_val = (size_t)m->n_scans * LIO_SUMS, bytes = n_val * sizeof(double);
-    for (lio_s2m_handle* ch : m->dev) { const int rc = lio_s2m_batch_begin(ch); if (rc != LIO_OK) return rc; }
-    for (int it = 0; it < h->cfg.max_iters; ++it) {                         // MO:1848
-        for (size_t c = 0; c < m->dev.size(); ++c) {
-            lio_s2m_handle* ch = m->dev[c];
-            const int rc = lio_s2m_batch_iter_partial(ch, m->d_part[c]);
-            if (rc != LIO_OK) return rc;
-            HIPCHK(hipMemcpyAsync(m->h_part[c], m->d_part[c], bytes, hipMemcpyDeviceToHost, ch->stream));
-        }
-        for (lio_s2m_handle* ch : m->dev) { HIPCHK(hipSetDevice(ch->cfg.device_id)); HIPCHK(hipStreamSynchronize(ch->stream)); }
-        for (size_t k = 0; k < n_val; ++k) {                                // fixed order: bitwise reproducible
-            double v = m->h_part[0][k];
-            for (size_t c = 1; c < m->dev.size(); ++c) v += m->h_part[c][k];
-            m->h_tot[k] = v;
-        }
-        for (size_t c = 0; c < m->dev.size(); ++c) {
-            lio_s2m_handle* ch = m->dev[c];
-            HIPCHK(hipSetDevice(ch->cfg.device_id));
-            HIPCHK(hipMemcpyAsync(m->d_tot[c], m->h_tot, bytes, hipMemcpyHostToDevice, ch->stream));
-            const int rc = lio_s2m_batch_iter_apply(ch, m->d_tot[c]);
-            if (rc != LIO_OK) return rc;
-        }
-        int32_t active = 0;
-        const int rc = lio_s2m_batch_poll_active(m->dev[0], it, &active);   // every device solves the same sums
-        if (rc != LIO_OK) return rc;
-        if (active == 0) break;                                             // MO:1857-1858 for every scan
-    }
-    for (lio_s2m_handle* ch : m->dev) { const int rc = lio_s2m_batch_sync(ch); if (rc != LIO_OK) return rc; }
-    h->ran = true;
     return LIO_OK;
 }
 
@@ -1552,7 +1100,7 @@ extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
     LioIterParams Pcs;
     const bool with_corners = h->corner_active && h->corner->n_blocks > 0;
     if (with_corners) lio_fill_params_corner(h, Pcs, d_sums);
-    if (P.blk_skip && !h->split && !getenv("LIO_NO_CULL")) {
+    if (P.blk_skip && !getenv("LIO_NO_CULL")) {
         lio_launch_shard_cull(P, h->plan_ranks, h->plan_rank, h->plan_halo, h->plan_bounds, h->d_block_box, h->n_blocks, h->d_blk_skip,
                               h->stream);
         if (getenv("LIO_CULL_STATS")) {                  // diagnostics only (synchronises)
@@ -1580,11 +1128,16 @@ extern "C" int lio_s2m_batch_iter_partial(lio_s2m_handle* h, double* d_sums)
 
 extern "C" int lio_s2m_batch_iter_apply(lio_s2m_handle* h, const double* d_sums)
 {
-    if (!h || !d_sums) return lio_fail(LIO_ERR_ARG, "null argument");
+    return lio_s2m_iter_apply_slots(h, d_sums, 0, 1);
+}
+
+int lio_s2m_iter_apply_slots(lio_s2m_handle* h, const double* d_sums, size_t slot_stride, int n_slots)
+{
+    if (!h || !d_sums || n_slots < 1) return lio_fail(LIO_ERR_ARG, "null argument");
     if (!h->ran || h->launches_this_run < 1) return lio_fail(LIO_ERR_ARG, "batch_iter_partial first");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();
-    lio_launch_apply(h->d_state, h->n_scans, d_sums, h->c, h->d_active, h->stream);
+    lio_launch_apply(h->d_state, h->n_scans, d_sums, slot_stride, n_slots, h->c, h->d_active, h->stream);
     // publish the number of still-iterating scans after this iteration (see lio_s2m_batch_poll_active)
     const int it = h->launches_this_run - 1;
     if (it < LIO_MAX_ITERS) {
@@ -1619,10 +1172,7 @@ extern "C" int lio_s2m_batch_n_active(lio_s2m_handle* h, int32_t* n_active)
 extern "C" int lio_s2m_batch_sync(lio_s2m_handle* h)
 {
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
-    if (h->multi) {
-        for (lio_s2m_handle* ch : h->multi->dev) { const int rc = lio_s2m_batch_sync(ch); if (rc != LIO_OK) return rc; }
-        return LIO_OK;
-    }
+    if (h->multi) return lio_multi_sync(h);
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     { const int rcc = lio_run_continue(h, true); if (rcc != LIO_OK) return rcc; }
@@ -1634,16 +1184,7 @@ extern "C" int lio_s2m_batch_sync(lio_s2m_handle* h)
 extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_result* results)
 {
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
-    if (h->multi) {
-        if (!h->ran) return lio_fail(LIO_ERR_ARG, "nothing has been run");
-        // every device holds the same per-scan state; the others are read as well so that their host mirrors
-        // (persistent matP / isDegenerate, MO:176-177) stay current
-        int rc = LIO_OK;
-        for (size_t c = h->multi->dev.size(); c-- > 0 && rc == LIO_OK;)
-            rc = lio_s2m_batch_results(h->multi->dev[c], c == 0 ? poses : nullptr, c == 0 ? results : nullptr);
-        h->prof = h->multi->dev[0]->prof;
-        return rc;
-    }
+    if (h->multi) return lio_multi_results(h, poses, results);
     if (!h->ran) return lio_fail(LIO_ERR_ARG, "nothing has been run");
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
@@ -1679,10 +1220,28 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
     }
     HIPCHK(hipGetLastError());
     if (h->run_persist) {
-        // every scan leaves a one-launch loop done; one that did not gave up waiting at its barrier (bounded polls)
-        for (int s = 0; s < h->n_scans; ++s)
-            if (!h->h_state[s].done)
-                return lio_fail(LIO_ERR_HIP, "the one-launch loop gave up waiting for a solve (cfg.pipeline = 4); results are incomplete");
+        // Every scan leaves a one-launch loop done; one that did not gave up waiting at its barrier (bounded polls): its
+        // workgroups were not all resident (another client holds compute units) or never arrived.  Recover inside this
+        // call: clear the arrival counters the aborted launch left armed (every later run on this handle would otherwise
+        // find its "last workgroup" one arrival early -- round-2 advisor finding), and run the same registrations through
+        // the launch loop from the saved initial guesses (d_poses).  What the aborted launch may already have written into
+        // the persistent members (isDegenerate / matP of a first solve) is what the launch loop's first solve computes from
+        // the same sums, bit for bit, so nothing else needs restoring.
+        bool incomplete = false;
+        for (int s = 0; s < h->n_scans; ++s) incomplete = incomplete || !h->h_state[s].done;
+        if (incomplete) {
+            h->persist_fallbacks++;
+            h->prof.persist_fallbacks = h->persist_fallbacks;
+            HIPCHK(hipMemsetAsync(h->d_arrive, 0, h->cap_arrive * sizeof(unsigned), h->stream));
+            const bool keep_defer = h->defer_sync;
+            h->no_persist = true; h->defer_sync = true;
+            h->poses_set = true; h->pose_in_state = false;           // (k_s2m_init_state left the guesses in d_poses)
+            int rc = lio_s2m_batch_run(h);
+            h->defer_sync = keep_defer;
+            if (rc == LIO_OK) rc = lio_s2m_batch_results(h, poses, results);
+            h->no_persist = false;
+            return rc;
+        }
     }
     int64_t pit = 0;
     for (int s = 0; s < h->n_scans; ++s) {
@@ -1727,25 +1286,8 @@ extern "C" int lio_s2m_batch_results(lio_s2m_handle* h, float* poses, lio_s2m_re
     }
     h->prof.n_units = n_units;
     h->prof.unit_iters = h->unit_iters;
-    h->prof.pipeline = h->split ? 2 : (h->certk ? 3 : (h->run_persist ? 4 : (h->reusek ? 5 : 1)));
-    memset(h->prof.cert_points, 0, sizeof(h->prof.cert_points));
-    memset(h->prof.scan_points, 0, sizeof(h->prof.scan_points));
-    if (h->split && h->cfg.profile && h->d_split_stats && !h->v_groups.empty()) {
-        const size_t ng = h->v_groups.size();
-        std::vector<int> stt(ng * LIO_MAX_ITERS);
-        HIPCHK(hipMemcpy(stt.data(), h->d_split_stats, stt.size() * sizeof(int), hipMemcpyDeviceToHost));
-        for (int i = 0; i < LIO_MAX_ITERS; ++i) {
-            int64_t sc = 0, all = 0;
-            for (size_t g = 0; g < ng; ++g) {
-                sc += stt[(size_t)i * ng + g];
-                const LioScanState& st = h->h_state[h->v_groups[g].scan];
-                const int ran = st.status == 1 ? 0 : (st.status == 2 ? 1 : st.iter);
-                if (i < ran) all += h->v_groups[g].n;
-            }
-            h->prof.cert_points[i] = all;
-            h->prof.scan_points[i] = sc;
-        }
-    }
+    h->prof.pipeline = h->run_persist ? 4 : 1;
+    h->prof.persist_fallbacks = h->persist_fallbacks;
     return LIO_OK;
 }
 
@@ -1774,6 +1316,19 @@ extern "C" int lio_s2m_register(lio_s2m_handle* h, const void* scan, size_t n, s
     return (res ? res : &local)->status;
 }
 
+// Field offsets of a PointCloud2 come off the wire: every comparison is written so that it cannot wrap (off + 12 > step
+// passes for off = 0xfffffff4 in 32-bit arithmetic -- round-2 advisor finding).
+int lio_pc2_check_xyz(const lio_pc2_layout* L)
+{
+    if (!L) return lio_fail(LIO_ERR_ARG, "null layout");
+    const uint32_t st = L->point_step;
+    if (st < 12 || (st & 3) || (L->off_x & 3) || L->off_x > st - 12)
+        return lio_fail(LIO_ERR_ARG, "x, y, z must be three consecutive FLOAT32 fields inside the record");
+    if (L->off_intensity >= 0 && ((L->off_intensity & 3) || (uint32_t)L->off_intensity > st - 4))
+        return lio_fail(LIO_ERR_ARG, "intensity must be a FLOAT32 field inside the record");
+    return LIO_OK;
+}
+
 // lio_s2m_register on a sensor_msgs/PointCloud2 `data` blob (cloud_info.cloud_deskewed, cloud_info.msg:27): what
 // pcl::fromROSMsg(msgIn->cloud_deskewed, *laserCloudSurfLast) MO:440 + scan2MapOptimization do, without the copy
 // into a pcl::PointCloud.  x, y, z are read in place at layout->off_x.
@@ -1781,8 +1336,7 @@ extern "C" int lio_s2m_register_pc2(lio_s2m_handle* h, const void* data, size_t 
                                     float pose[6], lio_s2m_result* res)
 {
     if (!h || !layout || !pose) return lio_fail(LIO_ERR_ARG, "null argument");
-    if (layout->point_step < 12 || (layout->point_step & 3) || (layout->off_x & 3) || layout->off_x + 12 > layout->point_step)
-        return lio_fail(LIO_ERR_ARG, "x, y, z must be three consecutive FLOAT32 fields inside the record");
+    if (lio_pc2_check_xyz(layout) != LIO_OK) return LIO_ERR_ARG;
     bool pinned = false;
     if (layout->pin_host && data && n_points) {
         HIPCHK(hipSetDevice(h->cfg.device_id));
@@ -1790,20 +1344,22 @@ extern "C" int lio_s2m_register_pc2(lio_s2m_handle* h, const void* data, size_t 
         (void)hipGetLastError();
     }
     h->xyz_off = layout->off_x;
+    h->int_off = layout->off_intensity >= 0 ? layout->off_intensity : -1;
     const int rc = lio_s2m_register(h, data, n_points, layout->point_step, pose, res);
     h->xyz_off = 0;
+    h->int_off = -2;
     if (pinned) (void)hipHostUnregister(const_cast<void*>(data));
     return rc;
 }
 
 // Internal (lio_mapbuild.hip): the staged records of batch slot `scan` as they were uploaded.
-int lio_s2m_staged_scan(lio_s2m_handle* h, int scan, const unsigned char** d_rec, size_t* n, size_t* stride, size_t* xyz_off,
+int lio_s2m_staged_scan(lio_s2m_handle* h, int scan, const unsigned char** d_rec, size_t* n, size_t* stride, size_t* xyz_off, int* int_off,
                         int* device_id, hipStream_t* stream)
 {
     if (!h || scan < 0 || scan >= h->n_scans || !h->last_stage) return lio_fail(LIO_ERR_ARG, "no such resident scan");
     const LioScanState& st = h->h_state[scan];
     *d_rec = h->last_stage + (size_t)st.offset * h->last_stride;
-    *n = (size_t)st.n_pts; *stride = h->last_stride; *xyz_off = h->last_xyz_off;
+    *n = (size_t)st.n_pts; *stride = h->last_stride; *xyz_off = h->last_xyz_off; *int_off = h->last_int_off;
     *device_id = h->cfg.device_id; *stream = h->stream;
     return LIO_OK;
 }
@@ -1836,30 +1392,7 @@ extern "C" int lio_s2m_get_correspondences(lio_s2m_handle* h, int32_t scan, uint
     if (!h) return lio_fail(LIO_ERR_ARG, "null handle");
     if (h->cfg.record_corr_iter < 0) return lio_fail(LIO_ERR_ARG, "record_corr_iter was not set at create time");
     if (scan < 0 || scan >= h->n_scans) return lio_fail(LIO_ERR_ARG, "scan slot out of range");
-    if (h->multi) {
-        // a point's record lives on the device that owned it in that iteration; neighbour indices come back in the
-        // caller's map order (a shard numbers its points locally)
-        LioMulti* m = h->multi;
-        const size_t n = (size_t)m->dev[0]->h_state[scan].n_pts;
-        std::vector<uint8_t> f(n);
-        std::vector<float> cf(n * 4);
-        std::vector<int32_t> nn(n * 5);
-        if (flag) memset(flag, 0, n);
-        if (coeff4) memset(coeff4, 0, n * 4 * sizeof(float));
-        if (nn_idx5) for (size_t i = 0; i < n * 5; ++i) nn_idx5[i] = -1;
-        for (size_t c = 0; c < m->dev.size(); ++c) {
-            const int rc = lio_s2m_get_correspondences(m->dev[c], scan, f.data(), cf.data(), nn.data());
-            if (rc != LIO_OK) return rc;
-            const std::vector<int>& idx = m->shard_idx[c];
-            for (size_t i = 0; i < n; ++i) {
-                if (nn[i * 5] < 0) continue;                                // not processed (not owned / gate failed) on this device
-                if (flag) flag[i] = f[i];
-                if (coeff4) memcpy(coeff4 + i * 4, cf.data() + i * 4, 4 * sizeof(float));
-                if (nn_idx5) for (int j = 0; j < 5; ++j) nn_idx5[i * 5 + j] = idx[(size_t)nn[i * 5 + j]];
-            }
-        }
-        return LIO_OK;
-    }
+    if (h->multi) return lio_multi_get_correspondences(h, scan, flag, coeff4, nn_idx5);
     HIPCHK(hipSetDevice(h->cfg.device_id));
     (void)hipGetLastError();   // drop stale codes left by other HIP users of this thread (e.g. hipErrorNotReady)
     { const int rcc = lio_run_continue(h, true); if (rcc != LIO_OK) return rcc; }   // (a run started by batch_run may still be pending)

@@ -34,7 +34,7 @@ def _one_round(pkg, case, flavour):
         p, _ = b.batch_results()
         a.close(); b.close()                      # the owner goes first: the sharer must not touch freed memory
     elif flavour == "cert":
-        s = pkg.ScanToMap(sort_scan=2, pipeline=3)
+        s = pkg.ScanToMap(sort_scan=2, pipeline=1)
         s.set_map(case["map"])
         s.batch_upload(scans); s.batch_set_poses(poses0); s.batch_run()
         p, _ = s.batch_results()

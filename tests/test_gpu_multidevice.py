@@ -73,3 +73,56 @@ def test_multi_device_with_a_smaller_gate_keeps_exact_neighbours(pkg, oracle, sm
     for a, b in zip(one.get_correspondences(0), many.get_correspondences(0)):
         np.testing.assert_array_equal(a, b)
     one.close(); many.close()
+
+
+def test_device_side_exchange_issues_no_stream_synchronisation(pkg, small_case, monkeypatch):
+    """The join of the per-scan sums (MO:1622-1686) happens on the devices: peer stores into every device's gather buffer,
+    cross-stream event waits, slots added in device order inside the solving kernel.  The host never synchronises a
+    stream inside the Gauss-Newton loop (lio_s2m_profile.multi_stream_syncs counts them) and looks at a convergence count
+    only `lookahead` iterations late; the copy form (no peer access) and the round-2 host form give the same bits."""
+    qs = small_case["queries"]
+    scans = [q["scan"] for q in qs]
+    poses0 = np.stack([q["pose_init"] for q in qs])
+    outs = {}
+    for ex in ("", "copy", "host"):
+        if ex:
+            monkeypatch.setenv("LIO_MULTI_EXCHANGE", ex)
+        else:
+            monkeypatch.delenv("LIO_MULTI_EXCHANGE", raising=False)
+        m = pkg.ScanToMap(n_devices=3, device_ids=[0, 0, 0])
+        m.set_map(small_case["map"])
+        m.batch_upload(scans); m.batch_set_poses(poses0); m.batch_run()
+        p, r = m.batch_results()
+        pr = m.profile()
+        outs[ex] = (p, [x.iters for x in r], np.stack([np.array(x.matP) for x in r]), np.stack([np.array(x.AtA) for x in r]))
+        assert pr.multi_exchange == {"": 0, "copy": 1, "host": 2}[ex]
+        assert pr.multi_iterations >= max(outs[ex][1])
+        if ex != "host":
+            assert pr.multi_stream_syncs == 0
+            # lookahead 2: the first count looked at is the one after iteration 0, when iteration 3 is about to be enqueued
+            assert pr.multi_event_waits == pr.multi_iterations - 3 + (1 if pr.multi_iterations < m.cfg.max_iters else 0) or pr.multi_iterations <= 3
+        else:
+            assert pr.multi_stream_syncs == 3 * pr.multi_iterations
+        m.close()
+    for ex in ("copy", "host"):
+        for a, b in zip(outs[""], outs[ex]):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_multi_device_lookahead_never_changes_a_result(pkg, small_case):
+    qs = small_case["queries"]
+    scans = [q["scan"] for q in qs]
+    poses0 = np.stack([q["pose_init"] for q in qs])
+    ref = None
+    for look in (0, 1, 4):
+        m = pkg.ScanToMap(n_devices=2, device_ids=[0, 0], lookahead=look)
+        m.set_map(small_case["map"])
+        for rep in range(2):                               # the second run re-uses the gather buffers and events
+            m.batch_upload(scans); m.batch_set_poses(poses0); m.batch_run()
+            p, r = m.batch_results()
+            got = (p, [x.iters for x in r], [list(x.n_corr_iter) for x in r])
+            if ref is None:
+                ref = got
+            np.testing.assert_array_equal(ref[0], got[0])
+            assert ref[1:] == got[1:]
+        m.close()

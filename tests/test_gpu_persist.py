@@ -187,3 +187,50 @@ def test_speculation_on_isdegenerate_and_its_roll_back(pkg, synth, small_case, m
         _same_result(ra, rb)
         degs.append(rb.is_degenerate)
     assert degs == [1, 0, 0, 1, 1]
+
+
+@pytest.mark.parametrize("withhold", [0, 3])
+def test_a_timed_out_one_launch_loop_recovers_through_the_launch_loop(pkg, oracle, small_case, withhold):
+    """A workgroup that never arrives (test hook) makes its scan's other workgroups give up at the barrier after `spin_max`
+    polls.  The call must not fail: the arrival counters are cleared, the registration is re-run through the launch loop
+    from the saved initial guess inside the same call, the fall-back is counted, and the NEXT registrations on the same
+    handle -- one-launch again -- are bit-identical to the launch loop's and within tolerance of the oracle
+    (round-2 advisor finding: the aborted launch used to leave arrive[s] != 0 behind)."""
+    qs = small_case["queries"]
+    ref = pkg.ScanToMap(pipeline=1)
+    ref.set_map(small_case["map"])
+    h = pkg.ScanToMap(pipeline=4)
+    h.set_map(small_case["map"])
+    p0, r0, _ = h.scan2MapOptimization(qs[0]["scan"], qs[0]["pose_init"])            # a healthy run first
+    assert h.profile().pipeline == 4 and h.profile().persist_fallbacks == 0
+    h.debug_persist_spin(spin_max=64, withhold_wg=withhold)
+    pa, ra, rca = h.scan2MapOptimization(qs[1]["scan"], qs[1]["pose_init"])
+    pr = h.profile()
+    assert pr.persist_fallbacks == 1 and pr.pipeline == 1                            # recovered by the launch loop
+    pb, rb, rcb = ref.scan2MapOptimization(qs[0]["scan"], qs[0]["pose_init"])
+    pb, rb, rcb = ref.scan2MapOptimization(qs[1]["scan"], qs[1]["pose_init"])
+    assert rca == rcb
+    np.testing.assert_array_equal(pa, pb)
+    _same_result(ra, rb)
+    h.debug_persist_spin(spin_max=0, withhold_wg=-1)
+    for q in (qs[2], qs[0]):                                                         # the handle is healthy again
+        pa, ra, rca = h.scan2MapOptimization(q["scan"], q["pose_init"])
+        pb, rb, rcb = ref.scan2MapOptimization(q["scan"], q["pose_init"])
+        assert h.profile().pipeline == 4 and h.profile().persist_fallbacks == 1
+        np.testing.assert_array_equal(pa, pb)
+        _same_result(ra, rb)
+        po, ro, _, _ = oracle.scan2map(oracle.default_config(knn_mode=1, n_threads=8), q["scan"], small_case["map"], q["pose_init"])
+        assert ro.iters == ra.iters and np.abs(pa[3:] - po[3:]).max() <= 1e-5 and np.abs(pa[:3] - po[:3]).max() <= 1e-6
+    # a batch with the time-out in one scan only: every scan's result is still the launch loop's
+    scans = [q["scan"] for q in qs]
+    poses0 = np.stack([q["pose_init"] for q in qs])
+    h.debug_persist_spin(spin_max=64, withhold_wg=withhold)
+    h.batch_upload(scans); h.batch_set_poses(poses0); h.batch_run()
+    pm, rm = h.batch_results()
+    assert h.profile().persist_fallbacks == 2
+    ref.batch_upload(scans); ref.batch_set_poses(poses0); ref.batch_run()
+    pn, rn = ref.batch_results()
+    np.testing.assert_array_equal(pm, pn)
+    for a, b in zip(rm, rn):
+        _same_result(a, b)
+    ref.close(); h.close()
