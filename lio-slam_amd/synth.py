@@ -26,8 +26,9 @@ SENSORS = {
 
 
 # --------------------------------------------------------------------- scene
-def make_scene(seed=BASE_SEED, length=260.0, kind="street"):
-    """Returns boxes float32 [n,6] = (xmin,ymin,zmin,xmax,ymax,zmax); ground is z=0."""
+def make_scene(seed=BASE_SEED, length=260.0, kind="street", density=0.02):
+    """Returns boxes float32 [n,6] = (xmin,ymin,zmin,xmax,ymax,zmax); ground is z=0.
+    density: box obstacles per m^2 of street (0.02)."""
     rng = np.random.Generator(np.random.MT19937(seed))
     boxes = []
     x0 = -80.0
@@ -53,7 +54,7 @@ def make_scene(seed=BASE_SEED, length=260.0, kind="street"):
     boxes.append((x1, -17.0, 0.0, x1 + 1.5, 17.0, 12.0))
     # box obstacles, density 0.02 / m^2 over the street, keeping |y| > 2.5 m free
     area = (x1 - x0) * 16.0
-    n_obs = int(0.02 * area)
+    n_obs = int(density * area)
     for _ in range(n_obs):
         sx, sy, sz = rng.uniform(1.0, 4.0, 3)
         cx = rng.uniform(x0, x1)
@@ -248,12 +249,16 @@ def build_map(boxes, kf_poses, sensor="vlp16", seed=BASE_SEED, scan_leaf=0.4, ma
 
 
 def make_query(boxes, true_pose, sensor="vlp16", seed=0, scan_leaf=0.4,
-               guess_sigma=(0.10, math.radians(1.0)), device=None):
+               guess_sigma=(0.10, math.radians(1.0)), device=None, raw_out=None):
     """Query scan at true_pose, voxel-downsampled (downsampleCurrentScan MO:1605-1611),
-    and a perturbed initial guess.  Returns (scan_xyz f32 [N_s,3], pose_init f32[6])."""
+    and a perturbed initial guess.  Returns (scan_xyz f32 [N_s,3], pose_init f32[6]).
+    scan_leaf <= 0: PCL's pass-through (the leaf overflows the voxel index, config/6t.yaml:112): the raw cloud.
+    raw_out (a list): also receives the un-downsampled sweep as float32 [n,4] x,y,z,intensity (cloud_deskewed)."""
     rng = np.random.Generator(np.random.MT19937(seed + 17))
     sc = cast_scan(boxes, true_pose, sensor, seed=seed, device=device)
-    ds = voxel_downsample(sc["xyz"], scan_leaf)
+    ds = voxel_downsample(sc["xyz"], scan_leaf) if scan_leaf > 0 else sc["xyz"]
+    if raw_out is not None:
+        raw_out.append(np.concatenate([sc["xyz"], sc["intensity"][:, None]], 1).astype(np.float32))
     init = np.array(true_pose, np.float64)
     init[3:6] += rng.normal(0, guess_sigma[0], 3)
     init[0:3] += rng.normal(0, guess_sigma[1], 3)
@@ -261,17 +266,23 @@ def make_query(boxes, true_pose, sensor="vlp16", seed=0, scan_leaf=0.4,
 
 
 def make_case(sensor="vlp16", n_keyframes=10, seed=BASE_SEED, kind="street", n_queries=1,
-              lawnmower=False, device=None, progress=None, sensor_override=None, q_range=None, with_map=True, workers=1):
+              lawnmower=False, device=None, progress=None, sensor_override=None, q_range=None, with_map=True, workers=1,
+              scan_leaf=0.4, map_leaf=0.5, density=0.02, n_raw=0):
     """One registration workload: map + n_queries (scan, true pose, initial guess).
 
     q_range=(a, b): only queries a..b-1 are ray-cast (the others are None) -- the ranks of a multi-GPU bench
-    each generate their share; every query is the same whichever rank makes it.  with_map=False skips the map."""
+    each generate their share; every query is the same whichever rank makes it.  with_map=False skips the map.
+    scan_leaf / map_leaf: mappingSurfLeafSize / surroundingKeyframeMapLeafSize (0.4 / 0.5 in lio_sam_default.yaml:56,71;
+    the keyframe clouds are filtered with scan_leaf as MO:2136-2142 stores laserCloudSurfLastDS); density: obstacles per m^2;
+    n_raw: the first n_raw queries also keep their raw sweep ("raw": [n,4] x,y,z,intensity)."""
     sensor = sensor_override or sensor
     length = max(60.0, float(n_keyframes) + 20.0) if not lawnmower else 80.0
-    boxes = make_scene(seed, length=length, kind=kind)
+    boxes = make_scene(seed, length=length, kind=kind, density=density)
     kfs = keyframe_poses(n_keyframes, seed=seed, lawnmower=lawnmower)
     kept = []
-    map_xyz = build_map(boxes, kfs, sensor, seed=seed, device=device, progress=progress, keep=kept) if with_map else None
+    kf_leaf = scan_leaf if scan_leaf > 0 else 0.05          # (a pass-through keyframe cloud would be ~115 k points each)
+    map_xyz = build_map(boxes, kfs, sensor, seed=seed, device=device, progress=progress, keep=kept,
+                        scan_leaf=kf_leaf, map_leaf=map_leaf) if with_map else None
     rng = np.random.Generator(np.random.MT19937(seed + 29))
     # along the path, 0.5 m past a keyframe (the last one for q == 0); drawn for all queries up front
     ks = [n_keyframes - 1 if q == 0 else int(rng.integers(0, n_keyframes)) for q in range(n_queries)]
@@ -281,8 +292,12 @@ def make_case(sensor="vlp16", n_keyframes=10, seed=BASE_SEED, kind="street", n_q
         tp = np.array(kfs[ks[q]], np.float64)
         tp[3] += 0.5 * math.cos(tp[2])
         tp[4] += 0.5 * math.sin(tp[2])
-        scan, init = make_query(boxes, tp, sensor, seed=seed + 5000 + q, device=device)
-        return {"scan": scan, "pose_true": tp.astype(np.float32), "pose_init": init}
+        raw = [] if q < n_raw else None
+        scan, init = make_query(boxes, tp, sensor, seed=seed + 5000 + q, device=device, scan_leaf=scan_leaf, raw_out=raw)
+        out = {"scan": scan, "pose_true": tp.astype(np.float32), "pose_init": init}
+        if raw:
+            out["raw"] = raw[0]
+        return out
 
     todo = [q for q in range(n_queries) if a <= q < b]
     if workers > 1 and len(todo) > 8:

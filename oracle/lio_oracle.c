@@ -310,7 +310,7 @@ static float lo_norm_tail(const float a[5][3], int col, int from)
     return sqrtf(s);
 }
 
-void lo_colpiv_qr_solve_5x3(const float A[15], const float b[5], float x[3])
+static void lo_colpiv_qr_impl_5x3(const float A[15], const float b[5], float x[3], int32_t *perm_out, float *rdiag_out, int32_t *nzp_out)
 {
     enum { R = 5, C = 3 };
     float qr[5][3], hc[3], direct[3], updated[3], c[5];
@@ -388,6 +388,9 @@ void lo_colpiv_qr_solve_5x3(const float A[15], const float b[5], float x[3])
     for (int k = 0; k < C; ++k) perm[k] = k;
     for (int k = 0; k < C; ++k) { int t = perm[k]; perm[k] = perm[trans[k]]; perm[trans[k]] = t; }
 
+    if (perm_out) for (int k = 0; k < C; ++k) { perm_out[k] = perm[k]; rdiag_out[k] = qr[k][k]; }
+    if (nzp_out) *nzp_out = nonzero_pivots;
+
     /* solve */
     x[0] = x[1] = x[2] = 0.0f;
     if (nonzero_pivots == 0) return;
@@ -410,6 +413,21 @@ void lo_colpiv_qr_solve_5x3(const float A[15], const float b[5], float x[3])
         }
     }
     for (int i = 0; i < nonzero_pivots; ++i) x[perm[i]] = c[i];
+}
+
+void lo_colpiv_qr_solve_5x3(const float A[15], const float b[5], float x[3])
+{
+    lo_colpiv_qr_impl_5x3(A, b, x, NULL, NULL, NULL);
+}
+
+/* Test hook (tests/test_oracle_math.py): the column order the factorisation chose (perm[k] = original column that ended
+ * up in position k), the diagonal of R and Eigen's nonzeroPivots() -- compared against LAPACK sgeqp3 through scipy, an
+ * implementation that shares no code and no author with this file. */
+void lo_colpiv_qr_debug_5x3(const float A[15], int32_t perm[3], float rdiag[3], int32_t *nonzero_pivots)
+{
+    const float b[5] = { -1.0f, -1.0f, -1.0f, -1.0f, -1.0f };
+    float x[3];
+    lo_colpiv_qr_impl_5x3(A, b, x, perm, rdiag, nonzero_pivots);
 }
 
 /* ------------------------------------------------------- OpenCV restatements */

@@ -89,6 +89,7 @@ void lo_point_associate(const float T[12], const float pi[3], float po[3]);
 
 /* Eigen::Matrix<float,5,3>::colPivHouseholderQr().solve(b)  (Eigen 3.3 semantics) */
 void lo_colpiv_qr_solve_5x3(const float A[15] /*row-major 5x3*/, const float b[5], float x[3]);
+void lo_colpiv_qr_debug_5x3(const float A[15], int32_t perm[3], float rdiag[3], int32_t *nonzero_pivots);   /* test hook */
 
 /* cv::solve(A,b,x,DECOMP_QR) for 6x6 CV_32F; returns 0 when singular (x=0) */
 int  lo_solve6_qr(const float A[36], const float b[6], float x[6]);

@@ -79,6 +79,7 @@ class Oracle:
         L.lo_get_transformation.argtypes = [C.c_float] * 6 + [_f32p, C.c_int]
         L.lo_point_associate.argtypes = [_f32p, _f32p, _f32p]
         L.lo_colpiv_qr_solve_5x3.argtypes = [_f32p, _f32p, _f32p]
+        L.lo_colpiv_qr_debug_5x3.argtypes = [_f32p, _i32p, _f32p, C.POINTER(C.c_int32)]
         L.lo_solve6_qr.argtypes = [_f32p, _f32p, _f32p]
         L.lo_eigen6_sym.argtypes = [_f32p, _f32p, _f32p]
         L.lo_inv6_lu.argtypes = [_f32p, _f32p]
@@ -168,6 +169,14 @@ class Oracle:
         self.lib.lo_colpiv_qr_solve_5x3(np.ascontiguousarray(A, np.float32).reshape(15),
                                         np.ascontiguousarray(b, np.float32), x)
         return x
+
+    def qr_pivots_5x3(self, A):
+        """Column order, diag(R) and nonzeroPivots() of the ColPivHouseholderQR restatement (test hook)."""
+        perm = np.zeros(3, np.int32)
+        rd = np.zeros(3, np.float32)
+        nz = C.c_int32(0)
+        self.lib.lo_colpiv_qr_debug_5x3(np.ascontiguousarray(A, np.float32).reshape(15), perm, rd, C.byref(nz))
+        return perm, rd, int(nz.value)
 
     def solve6(self, A, b):
         x = np.zeros(6, np.float32)

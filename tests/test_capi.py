@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} is declared in include/liogpu.h but not exported"
-    assert lib.lio_version() == 100
+    assert lib.lio_version() == 101
 
 
 def test_struct_layouts_match_c(pkg):
@@ -38,6 +38,7 @@ def test_struct_layouts_match_c(pkg):
                offsetof(lio_s2m_result, pose_iter), offsetof(lio_s2m_profile, point_iters));
         printf("%zu %zu %zu %zu\n", sizeof(lio_feature_config), sizeof(lio_range_image_config),
                offsetof(lio_s2m_config, nn_cache), offsetof(lio_range_image_config, lidarMaxRange));
+        printf("%zu %zu\n", offsetof(lio_s2m_profile, persist_fallbacks), offsetof(lio_s2m_profile, multi_stream_syncs));
         return 0;
     }'''
     with tempfile.TemporaryDirectory() as d:
@@ -50,8 +51,9 @@ def test_struct_layouts_match_c(pkg):
     assert sizes[:4] == [C.sizeof(pkg.S2MConfig), C.sizeof(pkg.S2MResult), C.sizeof(pkg.S2MProfile), C.sizeof(pkg.DeskewConfig)]
     assert sizes[4:8] == [pkg.S2MConfig.plane_tol.offset, pkg.S2MConfig.cell_div.offset,
                           pkg.S2MResult.pose_iter.offset, pkg.S2MProfile.point_iters.offset]
-    assert sizes[8:] == [C.sizeof(pkg.FeatureConfig), C.sizeof(pkg.RangeImageConfig),
-                         pkg.S2MConfig.nn_cache.offset, pkg.RangeImageConfig.lidarMaxRange.offset]
+    assert sizes[8:12] == [C.sizeof(pkg.FeatureConfig), C.sizeof(pkg.RangeImageConfig),
+                           pkg.S2MConfig.nn_cache.offset, pkg.RangeImageConfig.lidarMaxRange.offset]
+    assert sizes[12:] == [pkg.S2MProfile.persist_fallbacks.offset, pkg.S2MProfile.multi_stream_syncs.offset]
 
 
 def test_defaults_are_the_reference_literals(pkg):

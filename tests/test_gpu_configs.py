@@ -30,6 +30,30 @@ def test_config2_vlp16_vs_50_keyframes(pkg, oracle, vlp16_50kf):
     s2m.close()
 
 
+def test_config1_vlp16_vs_one_keyframe_map(pkg, oracle, synth):
+    """configs[0] (the reference's own CPU-runnable case) through the HIP path: VLP-16 16x1800 scan vs a ONE-keyframe map,
+    MO:1841-1846 the first time they let a registration through.  Association, iteration counts, matP bit-exact vs the
+    oracle; both the one-launch loop (what a lone registration takes by default) and the launch loop."""
+    case = synth.make_case("vlp16", n_keyframes=1, seed=20241022, device="cpu", n_queries=2)
+    cfg = oracle.default_config(knn_mode=1, n_threads=8)
+    for pipe in (0, 1):
+        s2m = pkg.ScanToMap(record_corr_iter=0, pipeline=pipe)
+        s2m.set_map(case["map"])
+        for q in case["queries"]:
+            pose, res, rc = s2m.scan2MapOptimization(q["scan"], q["pose_init"])
+            flag, coeff, nn = s2m.get_correspondences(0)
+            pose_o, res_o, matP_o, corr = oracle.scan2map(cfg, q["scan"], case["map"], q["pose_init"], corr_iter=0)
+            assert rc == res_o.status == 0 and res.iters == res_o.iters and res.converged == 1 and res.is_degenerate == res_o.is_degenerate
+            assert list(res.n_corr_iter) == list(res_o.n_corr_iter)
+            assert np.array_equal(flag, corr[0]) and np.array_equal(nn, corr[2])
+            assert np.array_equal(coeff[flag == 1].view(np.uint32), corr[1][flag == 1].view(np.uint32))
+            np.testing.assert_array_equal(np.array(res.matP, np.float32).view(np.uint32), np.asarray(matP_o, np.float32).reshape(-1).view(np.uint32))
+            assert np.abs(pose[3:] - pose_o[3:]).max() <= TOL_T and np.abs(pose[:3] - pose_o[:3]).max() <= TOL_R
+            assert np.abs(pose[3:] - q["pose_true"][3:]).max() < 0.08
+        assert s2m.profile().pipeline == (4 if pipe == 0 else 1)
+        s2m.close()
+
+
 def _gpu_case(synth, sensor, n_keyframes, n_queries, seed, **kw):
     """Synthetic case ray-cast on the GPU (as bench.py does): full-size configs in seconds instead of minutes."""
     return synth.make_case(sensor, n_keyframes=n_keyframes, seed=seed, device="cuda", n_queries=n_queries, workers=8, **kw)

@@ -74,3 +74,23 @@ def test_force_all_iters(oracle, small_case):
     q = small_case["queries"][0]
     pose, res, _, _ = oracle.scan2map(oracle.default_config(force_all_iters=1, max_iters=9), q["scan"], small_case["map"], q["pose_init"])
     assert res.iters == 9 and res.converged == 1
+
+
+def test_config0_vlp16_scan_vs_one_keyframe_map(oracle, synth):
+    """BASELINE.json configs[0]: a single VLP-16 16x1800 scan against a ONE-keyframe local map -- the second scan a node ever
+    sees (the guards MO:1841-1846 pass for the first time: one keyframe exists, the map is that keyframe's cloud through
+    VoxelGrid 0.4 then 0.5).  CPU plumbing config: the oracle recovers the pose, brute force and kd-tree agree."""
+    case = synth.make_case("vlp16", n_keyframes=1, seed=20241022, device="cpu", n_queries=2)
+    assert 2000 < len(case["map"]) < 9000                        # SURVEY 8: N_m ~ 4-8 k for one keyframe
+    for q in case["queries"]:
+        assert 2000 < len(q["scan"]) < 9000
+        a = oracle.scan2map(oracle.default_config(knn_mode=1, n_threads=4), q["scan"], case["map"], q["pose_init"], corr_iter=0)
+        b = oracle.scan2map(oracle.default_config(knn_mode=0, n_threads=4), q["scan"], case["map"], q["pose_init"], corr_iter=0)
+        np.testing.assert_array_equal(a[0], b[0])
+        for x, y in zip(a[3], b[3]):
+            np.testing.assert_array_equal(x, y)
+        pose, res = a[0], a[1]
+        assert res.status == 0 and res.converged == 1 and res.is_degenerate == 0 and res.n_corr_last > 500
+        # the map is one sparse keyframe 0.5 m behind the query: a coarser answer than against 50 keyframes, still centimetres
+        assert np.abs(pose[3:] - q["pose_true"][3:]).max() < 0.08, (pose, q["pose_true"])
+        assert np.abs(pose[:3] - q["pose_true"][:3]).max() < 0.05        # (pitch is weakly constrained by one VLP-16 keyframe)
