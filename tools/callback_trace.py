@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""One mapping callback as the patched node issues it: extractCloud from 200 resident keyframes (lio_assemble_map_resident),
+downsampleCurrentScan + scan2MapOptimization from the RAW deskewed 64x1800 cloud as one device chain
+(lio_s2m_register_raw), transformUpdate.  Wall time per phase; run under `rocprofv3 --kernel-trace` and summarise with
+tools/prof_summary.py for the per-kernel split.   python tools/callback_trace.py"""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("lio-slam_amd")
+synth = importlib.import_module("lio-slam_amd.synth")
+N = 16
+case = synth.make_case("hdl64", n_keyframes=200, seed=synth.BASE_SEED, n_queries=N, device="cuda", workers=8, n_raw=N)
+kc = [np.concatenate([c, np.zeros((len(c), 1), np.float32)], 1) for c, _ in case["keyframes"]]
+kp = np.stack([p for _, p in case["keyframes"]])
+node = pkg.ScanToMap()
+store = pkg.KeyframeStore()
+ids = [store.add(c) for c in kc]
+recs = []
+for q in case["queries"]:
+    r = q["raw"]
+    rec = np.zeros((len(r), 8), np.float32)
+    rec[:, :3], rec[:, 3], rec[:, 4] = r[:, :3], 1.0, r[:, 3]
+    recs.append(rec)
+lay = pkg.PC2Layout(point_step=32, off_x=0, off_intensity=16, off_ring=-1, off_time=-1, pin_host=0)
+
+
+def loop():
+    ta = tr = 0.0
+    nds = 0
+    for i, q in enumerate(case["queries"]):
+        t0 = time.perf_counter()
+        store.assemble(ids, kp, 0.5, s2m=node, want_output=False)
+        t1 = time.perf_counter()
+        p, res, rc, nd = node.downsampleAndScan2MapOptimization(recs[i], len(recs[i]), lay, 0.4, q["pose_init"])
+        pkg.transform_update(p)
+        t2 = time.perf_counter()
+        ta += t1 - t0; tr += t2 - t1; nds += nd
+    return 1e3 * ta / N, 1e3 * tr / N, nds / N
+
+
+loop()
+a, r, nd = loop()
+print(f"callback: assemble {a:.3f} ms + downsample+register+transformUpdate {r:.3f} ms = {a + r:.3f} ms; raw {np.mean([len(x) for x in recs]):.0f} points -> N_s {nd:.0f}; "
+      f"pipeline {node.profile().pipeline}, fallbacks {node.profile().persist_fallbacks}")
