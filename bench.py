@@ -536,6 +536,18 @@ def main():
         if (tj.get("scans_per_step"), tj.get("N_m")) == (B, int(len(map_xyz))):
             traffic = tj["hbm_bytes_per_launch"]      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, see DESIGN.md
 
+    # The roofline of the resource that actually binds the kernel: vector-ALU issue, with the texture addresser next to it.
+    # Counter-derived (SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE, GRBM_TA_BUSY need rocprofv3 --pmc passes), so it is a STORED figure
+    # of the builder's profiling session for this exact workload, like `roofline.traffic`; see tools/issue_roofline.py.
+    issue = None
+    ipath = os.path.join(ROOT, "profiles", "r03_issue_roofline.json")
+    if os.path.exists(ipath) and traffic is not None:
+        issue = json.load(open(ipath))
+        issue["source"] = ("stored figure: separate rocprofv3 --pmc passes of `bench.py --roofline-pass-only` by the builder (profiles/r03_pmc_SQ.txt, "
+                           "r03_pmc_SQ2.txt, tools/issue_roofline.py), same workload as this run (scans_per_step, N_m checked); not a counter of this run")
+        issue["note"] = ("k_s2m_iterate issues a vector instruction in two of every three cycles of every SIMD while its divergent 16-byte candidate "
+                         "gathers keep the texture addresser busy 79 % of the time: it sits on both limiters, HBM is at 11 %")
+
     out = {
         "metric": "scan-to-map registrations/sec, 64x1800 scan vs 200-keyframe map; pose RMSE",
         "value": value, "unit": "registrations/s", "n_gpus": world * n_dev, "steps": args.steps,
@@ -573,7 +585,7 @@ def main():
             "ms_per_launch": ms_per_launch,
             "limiter": "not HBM: VALU issue (about 2100 vector instructions per 64 live points and iteration, of which the candidate "
                        "scan is ~40 % and the bit-exact plane fit ~40 %) with the divergent candidate gathers keeping the texture "
-                       "addresser ~75 % busy; see DESIGN.md section 6",
+                       "addresser ~79 % busy; see `roofline_issue` and DESIGN.md section 6",
             "launches_per_step": int(live.sum()), "launches_per_graph_replay": int(args.graph), "algorithmic_bytes_per_launch": bytes_per_launch,
             "launches_measured": int(roof["launches"]) if roof else int(live.sum()),
             "in_streamed_region": in_stream,
@@ -583,6 +595,7 @@ def main():
                         "of the same steps.  (In the streamed region two batches' launch loops overlap on purpose, see in_streamed_region.)"
                         if not (sharded or inlib) else "HIP events around the launches of the last timed step" + (" on device 0" if inlib else ""),
         },
+        "roofline_issue": issue,
         "map_build_ms": prof0.map_build_ms, "map_upload_ms": prof0.map_upload_ms,
         "grid_cells": int(prof0.n_cells),
     }

@@ -67,6 +67,25 @@ public:
         return rc;
     }
 
+    // downsampleCurrentScan() MO:1605-1611 + the loop MO:1848-1859 in one device chain, from the blob of
+    // msgIn->cloud_deskewed (MO:440): `downSizeFilterSurf.filter(*laserCloudSurfLastDS)` runs on the GPU and the registration
+    // starts from its output without a host round trip.  laserCloudSurfLastDSNum = n_downsampled afterwards (MO:1610); pass
+    // laserCloudSurfLastDS->points.data() as ds_out (room for width*height PointType records) if the host copy is needed.
+    int downsampleAndScan2MapOptimization(const void* data, size_t width_times_height, uint32_t point_step, uint32_t off_x,
+                                          int32_t off_intensity, float mappingSurfLeafSize, void* ds_out = nullptr,
+                                          size_t ds_stride = 32, bool pin_host = false)
+    {
+        lio_pc2_layout lay{};
+        lay.point_step = point_step; lay.off_x = off_x; lay.off_intensity = off_intensity; lay.off_ring = -1; lay.off_time = -1;
+        lay.pin_host = pin_host ? 1 : 0;
+        const int rc = lio_s2m_register_raw(h_, data, width_times_height, &lay, mappingSurfLeafSize, transformTobeMapped, &last,
+                                            ds_out, ds_stride, &n_downsampled);
+        if (rc < 0) check(rc, "lio_s2m_register_raw");
+        isDegenerate = last.is_degenerate != 0;
+        return rc;
+    }
+    size_t n_downsampled = 0;
+
     // ---- extension beyond this reference (upstream LIO-SAM) ----
     // kdtreeCornerFromMap->setInputCloud(laserCloudCornerFromMapDS)
     void setInputCloudCorner(const void* pts, size_t n, size_t stride_bytes)
