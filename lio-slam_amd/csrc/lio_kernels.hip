@@ -999,40 +999,9 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
             P.d5_cache[ci] = ok ? lio_key_d2(top.k4) : -1.0f;
         float cxx = 0.0f, cyy = 0.0f, czz = 0.0f, cww = 0.0f;
         bool accept = false;
-        if (ok) {
-            // MO:1642-1646: neighbours in the caller's map order (original xyz)
-            float a[5][3], m[5][3];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const float4 mp = P.map_xyz4[nn[j]];
-                m[j][0] = a[j][0] = mp.x;
-                m[j][1] = a[j][1] = mp.y;
-                m[j][2] = a[j][2] = mp.z;
-            }
-            if (CORNER) {
-                accept = lio_corner_assoc(m, qx[pp], qy[pp], qz[pp], P.c.weight, P.c.min_s, cxx, cyy, czz, cww);
-            } else {
-                float X0[3];
-                lio_plane_qr5x3(a, X0);                                  // MO:1648
-                float pa = X0[0], pb = X0[1], pc = X0[2], pd = 1;         // MO:1650-1653
-                const float ps = sqrtf(pa * pa + pb * pb + pc * pc);      // MO:1655
-                pa /= ps; pb /= ps; pc /= ps; pd /= ps;                   // MO:1656
-                bool planeValid = true;                                   // MO:1658-1666
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    const float v = fabsf(pa * m[j][0] + pb * m[j][1] + pc * m[j][2] + pd);
-                    if ((double)v > P.c.plane_tol) planeValid = false;
-                }
-                if (planeValid) {
-                    const float pd2 = pa * qx[pp] + pb * qy[pp] + pc * qz[pp] + pd;   // MO:1669
-                    const float r2 = px[pp] * px[pp] + py[pp] * py[pp] + pz[pp] * pz[pp];
-                    // MO:1671-1672 (product, quotient and difference in double)
-                    const float s = (float)(1 - P.c.weight * (double)fabsf(pd2) / (double)sqrtf(sqrtf(r2)));
-                    cxx = s * pa; cyy = s * pb; czz = s * pc; cww = s * pd2;   // MO:1674-1677
-                    accept = (double)s > P.c.min_s;                       // MO:1679
-                }
-            }
-        }
+        // plane through the five neighbours, plane test, weight, coefficients MO:1642-1683 (the CORNER extension: point-to-line);
+        // the same function the one-launch loop calls (lio_s2m_device.h): one copy of the arithmetic
+        if (ok) accept = lio_assoc_point<CORNER>(P, nn, qx[pp], qy[pp], qz[pp], px[pp], py[pp], pz[pp], cxx, cyy, czz, cww);
         if (record && inr[pp]) {
             // the record is kept in the CALLER's point order
             const int li = bd.first + pp * LIO_BLOCK + (int)threadIdx.x;

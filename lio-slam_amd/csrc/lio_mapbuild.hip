@@ -206,53 +206,57 @@ __global__ void k_vox_list(const int* __restrict__ start, const int* __restrict_
     if (k < n_keys && start[k + 1] > start[k]) list[rank[k]] = k;
 }
 
-// One wave per occupied voxel: order its points by input index (rank sort in LDS), stage them in
-// LDS, then one lane adds them up in that order in fp32 and divides by the count (PCL's
-// CentroidPoint accumulators).  Output position = rank of the voxel (ascending voxel index).
-#define LIO_VOX_SMALL 32     // voxels with at most this many points are handled one per THREAD (k_vox_centroid_small)
-#define LIO_VOX_WAVE 128     // up to this many: one per wave (rank sort); larger ones go to k_vox_centroid_large
-#define LIO_VOX_LARGE 4096   // one per workgroup (bitonic sort in LDS); beyond that a slow exact fallback
-__global__ __launch_bounds__(256) void k_vox_centroid(const float4* __restrict__ p, const int* __restrict__ start,
-                                                      const int* __restrict__ list, int n_out,
-                                                      const int* __restrict__ tmp, float4* __restrict__ out,
-                                                      int* __restrict__ large_list, int* __restrict__ n_large)
+// Order of a voxel's points = ascending input index (the order pcl::VoxelGrid's sorted index vector visits them in; the fp32
+// running sum depends on it).  The counting sort leaves a voxel's list in arrival order, so every POINT computes its place
+// in its voxel's list by counting the smaller indices there: one thread per point, contiguous cached reads, no LDS, no
+// divergent insertion sort -- 1.3 M threads instead of the 67 k of a thread-per-voxel sort (round 2: 55 us for that kernel
+// alone at one wave per SIMD; this one ~10 us).  Voxels above LIO_VOX_RANK_MAX points are left to k_vox_centroid_large.
+#define LIO_VOX_RANK_MAX 128 // voxels with at most this many points: k_vox_rank + one thread adds them up (k_vox_centroid_ordered)
+#define LIO_VOX_LARGE 4096   // above LIO_VOX_RANK_MAX: one workgroup per voxel (bitonic sort in LDS); beyond this a slow exact fallback
+__global__ __launch_bounds__(256) void k_vox_rank(const int* __restrict__ key_of, int n, const int* __restrict__ start,
+                                                  const int* __restrict__ tmp, int* __restrict__ order)
 {
-    __shared__ int s_idx[4][LIO_VOX_WAVE];
-    __shared__ __attribute__((aligned(16))) float4 s_pt[4][LIO_VOX_WAVE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int o = blockIdx.x * 4 + wave;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int key = key_of[i];
+    const int b = start[key], m = start[key + 1] - b;
+    if (m > LIO_VOX_RANK_MAX) return;
+    int r = 0;
+    for (int j = 0; j < m; ++j) r += (tmp[b + j] < i) ? 1 : 0;
+    order[b + r] = i;
+}
+
+// One thread per occupied voxel: add its points up in that order in fp32 and divide by the count (PCL's CentroidPoint
+// accumulators).  Output position = rank of the voxel (ascending voxel index).  Crowded voxels are queued.
+__global__ __launch_bounds__(256) void k_vox_centroid_ordered(const float4* __restrict__ p, const int* __restrict__ start,
+                                                              const int* __restrict__ list, int n_out, const int* __restrict__ order,
+                                                              float4* __restrict__ out, int* __restrict__ large_list, int* __restrict__ n_large)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= n_out) return;
     const int key = list[o];
     const int b = start[key], n = start[key + 1] - b;
-    if (n <= LIO_VOX_SMALL) return;                          // done by k_vox_centroid_small
-    if (n > LIO_VOX_WAVE) {                                  // queue for k_vox_centroid_large
-        if (lane == 0) large_list[atomicAdd(n_large, 1)] = o;
-        return;
-    }
+    if (n > LIO_VOX_RANK_MAX) { large_list[atomicAdd(n_large, 1)] = o; return; }
     float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
-    for (int j = lane; j < n; j += 64) s_idx[wave][j] = tmp[b + j];
-    __builtin_amdgcn_wave_barrier();
-    for (int j = lane; j < n; j += 64) {
-        const int v = s_idx[wave][j];
-        int r = 0;
-        for (int i = 0; i < n; ++i) r += (s_idx[wave][i] < v) ? 1 : 0;
-        s_pt[wave][r] = p[v];
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {                              // four gathers in flight, the additions stay in order
+        const float4 v0 = p[order[b + j]], v1 = p[order[b + j + 1]], v2 = p[order[b + j + 2]], v3 = p[order[b + j + 3]];
+        sx += v0.x; sy += v0.y; sz += v0.z; si += v0.w;
+        sx += v1.x; sy += v1.y; sz += v1.z; si += v1.w;
+        sx += v2.x; sy += v2.y; sz += v2.z; si += v2.w;
+        sx += v3.x; sy += v3.y; sz += v3.z; si += v3.w;
     }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-        for (int j = 0; j < n; ++j) {
-            const float4 v = s_pt[wave][j];
-            sx += v.x; sy += v.y; sz += v.z; si += v.w;
-        }
-        const float cnt = (float)n;
-        out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
-    }
+    for (; j < n; ++j) { const float4 v = p[order[b + j]]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
+    const float cnt = (float)n;
+    out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
 }
 
 // Crowded voxels (the rings next to the sensor put hundreds of returns into one 0.4 m voxel): one workgroup
 // per voxel, taken from the queue filled by k_vox_centroid.  Point indices are sorted with a bitonic network
-// in LDS, the points gathered in that order, and one lane adds them up (fp32 addition order is part of
-// the contract).  The queue order is arbitrary; every voxel writes its own output slot.
+// in LDS, the points gathered in that order, and FOUR lanes add them up, one per component (x, y, z, intensity are four
+// independent running sums; the order inside each is the contract): a 4 000-point voxel is a chain of 4 000 dependent
+// additions per component whichever way it is cut, but one lane carrying all four chains ran them back to back.
+// The queue order is arbitrary; every voxel writes its own output slot.
 __global__ __launch_bounds__(256) void k_vox_centroid_large(const float4* __restrict__ p, const int* __restrict__ start,
                                                             const int* __restrict__ list, const int* __restrict__ tmp,
                                                             float4* __restrict__ out, const int* __restrict__ large_list,
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(256) void k_vox_centroid_large(const float4* __rest
         const int key = list[o];
         const int b = start[key], n = start[key + 1] - b;
         float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+        float acc = 0.0f;                                    // lanes 0..3: the running sum of component threadIdx.x
         if (n <= LIO_VOX_LARGE) {
             int np = 2;
             while (np < n) np <<= 1;
@@ -285,10 +290,13 @@ __global__ __launch_bounds__(256) void k_vox_centroid_large(const float4* __rest
                 const int m = min(1024, n - c0);
                 for (int j = threadIdx.x; j < m; j += 256) s_pt[j] = p[s_idx[c0 + j]];
                 __syncthreads();
-                if (threadIdx.x == 0)
-                    for (int j = 0; j < m; ++j) { const float4 v = s_pt[j]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
+                if (threadIdx.x < 4) {
+                    const float* comp = reinterpret_cast<const float*>(s_pt) + threadIdx.x;
+                    for (int j = 0; j < m; ++j) acc += comp[j * 4];
+                }
                 __syncthreads();
             }
+            if (threadIdx.x < 4) reinterpret_cast<float*>(out + o)[threadIdx.x] = acc / (float)n;
         } else if (threadIdx.x < 64) {
             // more than 4096 points in one voxel: repeatedly pick the smallest input index above the previous one
             const int lane = threadIdx.x;
@@ -302,42 +310,12 @@ __global__ __launch_bounds__(256) void k_vox_centroid_large(const float4* __rest
                 if (lane == 0) { const float4 v = p[best]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
             }
         }
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && n > LIO_VOX_LARGE) {
             const float cnt = (float)n;
             out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
         }
         __syncthreads();
     }
-}
-
-// The common case -- a handful of points per voxel -- one thread per voxel: insertion-sort the point indices
-// in a private LDS slice (stride 33: conflict-free), then add the points up in that order.  A wave per voxel
-// spends its time on launch and latency: 67 k voxels of ~19 points took 0.4 ms that way, 64 voxels per wave
-// keep thousands of gathers in flight instead.
-__global__ __launch_bounds__(256) void k_vox_centroid_small(const float4* __restrict__ p, const int* __restrict__ start,
-                                                            const int* __restrict__ list, int n_out,
-                                                            const int* __restrict__ tmp, float4* __restrict__ out)
-{
-    __shared__ int s_idx[256 * (LIO_VOX_SMALL + 1)];
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= n_out) return;
-    const int key = list[o];
-    const int b = start[key], n = start[key + 1] - b;
-    if (n > LIO_VOX_SMALL) return;                           // done by k_vox_centroid (one wave per voxel)
-    int* s = s_idx + threadIdx.x * (LIO_VOX_SMALL + 1);
-    for (int j = 0; j < n; ++j) {                            // ascending input index
-        const int v = tmp[b + j];
-        int i = j - 1;
-        while (i >= 0 && s[i] > v) { s[i + 1] = s[i]; --i; }
-        s[i + 1] = v;
-    }
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
-    for (int j = 0; j < n; ++j) {
-        const float4 v = p[s[j]];
-        sx += v.x; sy += v.y; sz += v.z; si += v.w;
-    }
-    const float cnt = (float)n;
-    out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
 }
 
 __global__ void k_xyzi4_to_aos(const float4* __restrict__ src, int n, unsigned char* __restrict__ dst, size_t stride)
@@ -450,6 +428,10 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out,
     HIPCHK(hipMemcpyAsync(&no, rank.template as<int>() + g.n_keys, sizeof(int), hipMemcpyDeviceToHost, s));
     // (the scatter does not need the count: it runs while the host waits for it)
     hipLaunchKernelGGL(k_vox_scatter, dim3(nb), dim3(256), 0, s, key_of.template as<int>(), slot_of.template as<int>(), n, start.template as<int>(), tmp.template as<int>());
+    // every point's place in its voxel's list in ascending input index; slot_of has been consumed by the scatter and becomes
+    // that ordered list.  Needs nothing the host is waiting for, so it runs under the wait as well.
+    hipLaunchKernelGGL(k_vox_rank, dim3(nb), dim3(256), 0, s, key_of.template as<int>(), n, start.template as<int>(), tmp.template as<int>(),
+                       slot_of.template as<int>());
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(list.alloc(sizeof(int) * (size_t)(no ? no : 1)));
     HIPCHK(out.alloc(sizeof(float4) * (size_t)(no ? no : 1)));
@@ -458,10 +440,8 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out,
     HIPCHK(hipMemsetAsync(large.p, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_vox_list, dim3(nk), dim3(256), 0, s, start.template as<int>(), rank.template as<int>(), g.n_keys, list.template as<int>());
     if (no) {
-        hipLaunchKernelGGL(k_vox_centroid_small, dim3((no + 255) / 256), dim3(256), 0, s, d_in, start.template as<int>(), list.template as<int>(), no,
-                           tmp.template as<int>(), out.template as<float4>());
-        hipLaunchKernelGGL(k_vox_centroid, dim3((no + 3) / 4), dim3(256), 0, s, d_in, start.template as<int>(), list.template as<int>(), no,
-                           tmp.template as<int>(), out.template as<float4>(), large.template as<int>() + 1, large.template as<int>());
+        hipLaunchKernelGGL(k_vox_centroid_ordered, dim3((no + 255) / 256), dim3(256), 0, s, d_in, start.template as<int>(), list.template as<int>(), no,
+                           slot_of.template as<int>(), out.template as<float4>(), large.template as<int>() + 1, large.template as<int>());
         hipLaunchKernelGGL(k_vox_centroid_large, dim3(no < 1024 ? no : 1024), dim3(256), 0, s, d_in, start.template as<int>(), list.template as<int>(),
                            tmp.template as<int>(), out.template as<float4>(), large.template as<int>() + 1, large.template as<int>());
     }

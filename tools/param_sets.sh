@@ -22,12 +22,20 @@ one() { # tag, bench args...
     echo "$tag bench rc=$?"
     local R="$B --steps 6 --warmup 2 --roofline-pass-only"
     rm -rf /tmp/prof/p_$tag
-    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/p_$tag/kt -o runc -- $R > /dev/null 2> /tmp/p_$tag.err
+    echo "$tag bench done" >> $OUT/progress.log
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/p_$tag/kt -o runc -- $R > /dev/null 2> /tmp/p_$tag.err
     python tools/prof_summary.py /tmp/prof/p_$tag/kt k_s2m k_scan k_map > $OUT/kernel_stats_$tag.txt
-    timeout -k 10 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d /tmp/prof/p_$tag/tcc -- $R > /dev/null 2>&1
+    echo "$tag kernel trace done" >> $OUT/progress.log
+    timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d /tmp/prof/p_$tag/tcc -- $R > /dev/null 2>&1
     python tools/prof_summary.py /tmp/prof/p_$tag/tcc k_s2m_iterate > $OUT/pmc_TCC_$tag.txt
-    timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --output-format csv -d /tmp/prof/p_$tag/fs -- $R > /dev/null 2>&1
+    echo "$tag TCC pass done" >> $OUT/progress.log
+    # (FETCH_SIZE and WRITE_SIZE in ONE pass never finished on this pool: one derived counter per pass, as in tools/profile_round.sh)
+    timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof/p_$tag/fs -- $R > /dev/null 2>&1
+    echo "$tag FETCH pass rc=$?" >> $OUT/progress.log
+    timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof/p_$tag/ws -- $R > /dev/null 2>&1
+    echo "$tag WRITE pass rc=$?" >> $OUT/progress.log
     python tools/prof_summary.py /tmp/prof/p_$tag/fs k_s2m_iterate > $OUT/pmc_FETCH_$tag.txt
+    python tools/prof_summary.py /tmp/prof/p_$tag/ws k_s2m_iterate >> $OUT/pmc_FETCH_$tag.txt
     rm -f $CASE
     python tools/param_summary.py $OUT $tag >> $OUT/summary.txt
     tail -1 $OUT/summary.txt
