@@ -59,14 +59,14 @@ int main(int argc, char** argv)
                     pc2.transformTobeMapped[4], pc2.transformTobeMapped[5]);
 
         // ---- variant (a'): downsampleCurrentScan MO:1605-1611 + the loop as one device chain, from the blob.  The scan given to
-        //      this stub is already downsampled, so a leaf that only merges points closer than 1 cm leaves it (nearly) as it is;
+        //      this stub is already downsampled, so a leaf of half its spacing leaves it (nearly) as it is;
         //      what is shown is the call, the returned N_s and that the registration runs from the filter's output
         liogpu::ScanToMap raw;
         for (int k = 0; k < 6; ++k) raw.transformTobeMapped[k] = std::strtof(argv[3 + k], nullptr);
         raw.setInputCloud(laserCloudSurfFromMapDS.data(), laserCloudSurfFromMapDS.size(), sizeof(PointXYZI));
         std::vector<PointXYZI> ds(laserCloudSurfLastDS.size());
         raw.downsampleAndScan2MapOptimization(laserCloudSurfLastDS.data(), laserCloudSurfLastDS.size(), (uint32_t)sizeof(PointXYZI), 0, 16,
-                                              0.05f, ds.data(), sizeof(PointXYZI));
+                                              0.2f, ds.data(), sizeof(PointXYZI));
         std::printf("raw iters %d n_ds %zu of %zu converged %d\n", raw.last.iters, raw.n_downsampled, laserCloudSurfLastDS.size(), raw.last.converged);
 
         // ---- variant (b): several GPUs behind the same calls (here the one device listed twice)

@@ -9,7 +9,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("lio-slam_amd")
 synth = importlib.import_module("lio-slam_amd.synth")
 N = 16
-case = synth.make_case("hdl64", n_keyframes=200, seed=synth.BASE_SEED, n_queries=N, device="cuda", workers=8, n_raw=N)
+LEAF_S = float(sys.argv[1]) if len(sys.argv) > 1 else 0.4       # mappingSurfLeafSize
+LEAF_M = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5       # surroundingKeyframeMapLeafSize
+case = synth.make_case("hdl64", n_keyframes=200, seed=synth.BASE_SEED, n_queries=N, device="cuda", workers=8, n_raw=N,
+                       scan_leaf=LEAF_S, map_leaf=LEAF_M)
 kc = [np.concatenate([c, np.zeros((len(c), 1), np.float32)], 1) for c, _ in case["keyframes"]]
 kp = np.stack([p for _, p in case["keyframes"]])
 node = pkg.ScanToMap()
@@ -29,9 +32,9 @@ def loop():
     nds = 0
     for i, q in enumerate(case["queries"]):
         t0 = time.perf_counter()
-        store.assemble(ids, kp, 0.5, s2m=node, want_output=False)
+        store.assemble(ids, kp, LEAF_M, s2m=node, want_output=False)
         t1 = time.perf_counter()
-        p, res, rc, nd = node.downsampleAndScan2MapOptimization(recs[i], len(recs[i]), lay, 0.4, q["pose_init"])
+        p, res, rc, nd = node.downsampleAndScan2MapOptimization(recs[i], len(recs[i]), lay, LEAF_S, q["pose_init"])
         pkg.transform_update(p)
         t2 = time.perf_counter()
         ta += t1 - t0; tr += t2 - t1; nds += nd
@@ -40,5 +43,5 @@ def loop():
 
 loop()
 a, r, nd = loop()
-print(f"callback: assemble {a:.3f} ms + downsample+register+transformUpdate {r:.3f} ms = {a + r:.3f} ms; raw {np.mean([len(x) for x in recs]):.0f} points -> N_s {nd:.0f}; "
+print(f"callback (leaf {LEAF_S} / {LEAF_M}): assemble {a:.3f} ms + downsample+register+transformUpdate {r:.3f} ms = {a + r:.3f} ms; raw {np.mean([len(x) for x in recs]):.0f} points -> N_s {nd:.0f}; "
       f"pipeline {node.profile().pipeline}, fallbacks {node.profile().persist_fallbacks}")
