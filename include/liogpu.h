@@ -190,6 +190,11 @@ void *lio_host_alloc(size_t bytes);
 void  lio_host_free(void *p);
 int   lio_host_register(void *p, size_t bytes);
 int   lio_host_unregister(void *p);
+/* Device memory for callers that keep clouds in HBM between calls (memory of the handle's own device is read in place by
+ * lio_s2m_batch_upload*, lio_s2m_register_raw, lio_kf_store_add_device).  lio_device_upload is a synchronous H2D copy. */
+void *lio_device_alloc(int32_t device_id, size_t bytes);
+void  lio_device_free(int32_t device_id, void *p);
+int   lio_device_upload(int32_t device_id, void *dst, const void *src, size_t bytes);
 
 /* Persistent members MO:176-177 for batch slot `scan` (slot 0 = lio_s2m_register). */
 int  lio_s2m_set_degeneracy(lio_s2m_handle *h, int32_t scan, const float matP[36], int32_t is_degenerate);

@@ -8,9 +8,9 @@ fallback: a missing library or GPU raises.
 from .api import (LioError, ScanToMap, S2MConfig, S2MResult, S2MProfile, DeskewConfig,
                   lib_path, load_library, build_library, deskew, curvature, imu_deskew_info,
                   transform_update, pack_xyzirt, deskew_default_config, voxel_grid, assemble_map, KeyframeStore, STATUS_NAMES,
-                  extract_features, FeatureConfig, range_image, RangeImageConfig, PinnedBuffer, PC2Layout, deskew_pc2)
+                  extract_features, FeatureConfig, range_image, RangeImageConfig, PinnedBuffer, DeviceBuffer, PC2Layout, deskew_pc2)
 
 __all__ = ["LioError", "ScanToMap", "S2MConfig", "S2MResult", "S2MProfile", "DeskewConfig",
            "lib_path", "load_library", "build_library", "deskew", "curvature", "imu_deskew_info",
            "transform_update", "pack_xyzirt", "deskew_default_config", "voxel_grid", "assemble_map", "KeyframeStore", "STATUS_NAMES",
-           "extract_features", "FeatureConfig", "range_image", "RangeImageConfig", "PinnedBuffer", "PC2Layout", "deskew_pc2"]
+           "extract_features", "FeatureConfig", "range_image", "RangeImageConfig", "PinnedBuffer", "DeviceBuffer", "PC2Layout", "deskew_pc2"]

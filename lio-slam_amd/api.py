@@ -123,7 +123,7 @@ EXPORTS = [
     "lio_range_image_default_config", "lio_range_image",
     "lio_s2m_share_map", "lio_s2m_batch_upload_async", "lio_host_alloc", "lio_host_free", "lio_host_register",
     "lio_host_unregister", "lio_s2m_set_shard_plan", "lio_s2m_register_pc2", "lio_deskew_pc2", "lio_kf_store_add_device", "lio_kf_store_add_from_handle",
-    "lio_s2m_register_raw", "lio_s2m_debug_persist_spin",
+    "lio_s2m_register_raw", "lio_s2m_debug_persist_spin", "lio_device_alloc", "lio_device_free", "lio_device_upload",
 ]
 
 
@@ -157,6 +157,11 @@ def load_library():
     L.lio_host_alloc.restype = vp
     L.lio_host_free.argtypes = [vp]
     L.lio_host_free.restype = None
+    L.lio_device_alloc.argtypes = [i32, sz]
+    L.lio_device_alloc.restype = vp
+    L.lio_device_free.argtypes = [i32, vp]
+    L.lio_device_free.restype = None
+    L.lio_device_upload.argtypes = [i32, vp, vp, sz]
     L.lio_host_register.argtypes = [vp, sz]
     L.lio_host_unregister.argtypes = [vp]
     L.lio_s2m_batch_set_poses.argtypes = [vp, C.POINTER(f32)]
@@ -456,6 +461,31 @@ class ScanToMap:
         v = C.c_int32()
         _check(self.lib.lio_s2m_batch_n_active(self.h, C.byref(v)), "lio_s2m_batch_n_active")
         return v.value
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes on `device_id` holding a copy of a numpy array (a cloud that already lives in HBM)."""
+
+    def __init__(self, array, device_id=0):
+        self.lib = load_library()
+        self.device_id = int(device_id)
+        a = np.ascontiguousarray(array)
+        self.nbytes = a.nbytes
+        self.ptr = self.lib.lio_device_alloc(self.device_id, self.nbytes)
+        if not self.ptr:
+            raise LioError("lio_device_alloc failed")
+        _check(self.lib.lio_device_upload(self.device_id, self.ptr, a.ctypes.data, self.nbytes), "lio_device_upload")
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.lib.lio_device_free(self.device_id, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PinnedBuffer:

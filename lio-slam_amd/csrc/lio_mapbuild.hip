@@ -13,6 +13,7 @@
 #include "lio_pool.h"
 #include "lio_device_math.h"
 #include "lio_scan2.h"
+#include "lio_voxsort.h"
 
 int lio_fail_ext(int code, const char* what, hipError_t e);                    // liogpu_api.hip
 int lio_s2m_set_map_device_xyzi(lio_s2m_handle* h, const float4* d_xyzi, size_t n);   // liogpu_api.hip
@@ -355,7 +356,8 @@ struct LioKeep {
 namespace {
 typedef LioTemp Buf;         // temporaries come from the recycling pool (lio_pool.h)
 
-template <class B> struct LioVoxWs { B bbox, key_of, slot_of, count, start, rank, tiles, tmp, list, large; };
+template <class B> struct LioVoxWs { B bbox, key_of, slot_of, count, start, rank, tiles, tmp, list, large,
+                                     pairs_a, pairs_b, hist, blk_heads, seg_start, d_no, row_total; };   // (second row: the sorting form, lio_voxsort.h)
 
 float ord2f(unsigned u)
 {
@@ -363,6 +365,71 @@ float ord2f(unsigned u)
     float f;
     memcpy(&f, &v, 4);
     return f;
+}
+
+// Which form of K7 runs (results are bit-identical): the counting sort keeps arrays over the whole key space, the sorting form
+// (lio_voxsort.h) only over the points.  Auto: sort once the bounding box spans more than 4 M voxels -- a raw 100 m sweep at any
+// of the reference's scan leaves; the local map at leaf 0.5 m (~1 M voxels, 1.3 M points) stays with the counting sort, which is
+// faster there.  LIO_VOX_FORM=count|sort in the environment forces one (tests, A/B).
+static int lio_vox_form(long long n_keys)
+{
+    const char* e = getenv("LIO_VOX_FORM");                  // (read per call: the tests flip it)
+    const int forced = !e ? 0 : (!strcmp(e, "sort") ? 2 : (!strcmp(e, "count") ? 1 : 0));
+    if (forced == 2 || (forced == 1 && n_keys <= (1LL << 29))) return forced;
+    return n_keys > (4LL << 20) ? 2 : 1;
+}
+
+// The sorting form: keys -> stable LSD radix sort of (key, index) pairs -> segment heads -> in-order sums.  g describes the
+// voxel grid, n_keys its size (< 2^31).  `out` is allocated for the worst case (n voxels) so that the centroid kernels are
+// enqueued without waiting for the count; the one host wait (*n_out) comes last and overlaps them.
+template <class B>
+static int voxel_grid_sorted(const float4* d_in, int n, const LioVoxGrid& g, long long n_keys, B& out, int* n_out, hipStream_t s, LioVoxWs<B>& ws)
+{
+    int bits = 1;
+    while (bits < 31 && (1LL << bits) < n_keys) ++bits;
+    const int passes = (bits + 7) / 8, dbits = (bits + passes - 1) / passes;      // e.g. 25 bits -> 4 passes of 7
+    const unsigned mask = (1u << dbits) - 1u;
+    const int items = n > (1 << 18) ? 8 : 4;
+    const int tile = LIO_VS_THREADS * items, n_blocks = (n + tile - 1) / tile;
+    const int n_hblk = (n + 1023) / 1024;
+    HIPCHK(ws.pairs_a.alloc(sizeof(uint2) * (size_t)n));
+    HIPCHK(ws.pairs_b.alloc(sizeof(uint2) * (size_t)n));
+    HIPCHK(ws.hist.alloc(sizeof(int) * (size_t)LIO_VS_BINS * n_blocks));
+    HIPCHK(ws.blk_heads.alloc(sizeof(int) * (size_t)(n_hblk + 1)));
+    HIPCHK(ws.seg_start.alloc(sizeof(int) * ((size_t)n + 1)));
+    HIPCHK(ws.d_no.alloc(sizeof(int) * 2));
+    HIPCHK(ws.row_total.alloc(sizeof(int) * LIO_VS_BINS));
+    HIPCHK(ws.large.alloc(sizeof(int) * ((size_t)n + 1)));
+    HIPCHK(out.alloc(sizeof(float4) * (size_t)n));
+    LioVsGrid vg = { g.inv, g.min_b0, g.min_b1, g.min_b2, g.mul1, g.mul2 };
+    uint2 *a = ws.pairs_a.template as<uint2>(), *b = ws.pairs_b.template as<uint2>();
+    hipLaunchKernelGGL(k_vsort_keys, dim3((n + 255) / 256), dim3(256), 0, s, vg, d_in, n, a);
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * dbits;
+        int* hist = ws.hist.template as<int>();
+        if (items == 8) hipLaunchKernelGGL(k_vsort_hist<8>, dim3(n_blocks), dim3(LIO_VS_THREADS), 0, s, a, n, shift, mask, hist, n_blocks);
+        else hipLaunchKernelGGL(k_vsort_hist<4>, dim3(n_blocks), dim3(LIO_VS_THREADS), 0, s, a, n, shift, mask, hist, n_blocks);
+        int* row_total = ws.row_total.template as<int>();
+        hipLaunchKernelGGL(k_vsort_scan_rows, dim3(LIO_VS_BINS), dim3(256), 0, s, hist, n_blocks, row_total);
+        if (items == 8) hipLaunchKernelGGL(k_vsort_scatter<8>, dim3(n_blocks), dim3(LIO_VS_THREADS), 0, s, a, n, shift, mask, hist, row_total, n_blocks, b);
+        else hipLaunchKernelGGL(k_vsort_scatter<4>, dim3(n_blocks), dim3(LIO_VS_THREADS), 0, s, a, n, shift, mask, hist, row_total, n_blocks, b);
+        uint2* t = a; a = b; b = t;
+    }
+    int* d_no = ws.d_no.template as<int>();
+    HIPCHK(hipMemsetAsync(d_no, 0, 2 * sizeof(int), s));                          // [0] voxels, [1] crowded voxels queued
+    hipLaunchKernelGGL(k_vsort_head_count, dim3(n_hblk), dim3(256), 0, s, a, n, ws.blk_heads.template as<int>());
+    hipLaunchKernelGGL(k_vsort_scan_small, dim3(1), dim3(256), 0, s, ws.blk_heads.template as<int>(), n_hblk, d_no);
+    hipLaunchKernelGGL(k_vsort_head_emit, dim3(n_hblk), dim3(256), 0, s, a, n, ws.blk_heads.template as<int>(), d_no, ws.seg_start.template as<int>());
+    int no = 0;
+    HIPCHK(hipMemcpyAsync(&no, d_no, sizeof(int), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_vsort_centroid, dim3((n + 255) / 256), dim3(256), 0, s, d_in, a, ws.seg_start.template as<int>(), d_no,
+                       out.template as<float4>(), ws.large.template as<int>(), d_no + 1);
+    hipLaunchKernelGGL(k_vsort_centroid_large, dim3(n < 1024 * 64 ? (n + 63) / 64 : 1024), dim3(256), 0, s, d_in, a, ws.seg_start.template as<int>(),
+                       out.template as<float4>(), ws.large.template as<int>(), d_no + 1);
+    HIPCHK(hipStreamSynchronize(s));                                              // (`no`; the centroid kernels ran under this wait)
+    HIPCHK(hipGetLastError());
+    *n_out = no;
+    return LIO_OK;
 }
 
 // K7 on a device-resident float4 cloud.  *d_out receives a freshly allocated device array.
@@ -407,6 +474,11 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out,
               d2 = (int)floorf(mx[2] * inv) - g.min_b2 + 1;
     g.mul1 = d0; g.mul2 = d0 * d1;
     const long long n_keys_ll = (long long)d0 * d1 * d2;
+    if (n_keys_ll > 2147483647LL) return lio_fail_ext(LIO_ERR_CAPACITY, "voxel grid has more than 2^31 - 1 voxels", hipSuccess);
+    if (lio_vox_form(n_keys_ll) == 2) {
+        g.n_keys = 0;
+        return voxel_grid_sorted<B>(d_in, n, g, n_keys_ll, out, n_out, s, ws);
+    }
     if (n_keys_ll > (1LL << 29)) return lio_fail_ext(LIO_ERR_CAPACITY, "voxel grid has more than 2^29 voxels", hipSuccess);
     g.n_keys = (int)n_keys_ll;
     B &key_of = ws.key_of, &slot_of = ws.slot_of, &count = ws.count, &start = ws.start, &rank = ws.rank, &tiles = ws.tiles, &tmp = ws.tmp, &list = ws.list;
@@ -539,7 +611,8 @@ extern "C" void lio_kf_store_destroy(lio_kf_store* s)
     (void)hipDeviceSynchronize();
     if (s->d_pts) (void)hipFree(s->d_pts);
     LioKeep* keep[] = { &s->vws.bbox, &s->vws.key_of, &s->vws.slot_of, &s->vws.count, &s->vws.start, &s->vws.rank, &s->vws.tiles, &s->vws.tmp, &s->vws.list,
-                        &s->vws.large, &s->world, &s->ds, &s->d_kf, &s->d_poses, &s->d_chunks, &s->blk_box };
+                        &s->vws.large, &s->vws.pairs_a, &s->vws.pairs_b, &s->vws.hist, &s->vws.blk_heads, &s->vws.seg_start, &s->vws.d_no, &s->vws.row_total,
+                        &s->world, &s->ds, &s->d_kf, &s->d_poses, &s->d_chunks, &s->blk_box };
     for (LioKeep* k : keep) k->release();
     delete s;
 }
@@ -760,7 +833,8 @@ void lio_raw_ws_free(LioRawWs* w)
 {
     if (!w) return;
     LioKeep* keep[] = { &w->raw, &w->xyzi, &w->ds, &w->vws.bbox, &w->vws.key_of, &w->vws.slot_of, &w->vws.count, &w->vws.start, &w->vws.rank,
-                        &w->vws.tiles, &w->vws.tmp, &w->vws.list, &w->vws.large };
+                        &w->vws.tiles, &w->vws.tmp, &w->vws.list, &w->vws.large, &w->vws.pairs_a, &w->vws.pairs_b, &w->vws.hist,
+                        &w->vws.blk_heads, &w->vws.seg_start, &w->vws.d_no, &w->vws.row_total };
     for (LioKeep* k : keep) k->release();
     delete w;
 }

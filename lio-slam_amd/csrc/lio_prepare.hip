@@ -151,7 +151,12 @@ __global__ __launch_bounds__(256) void k_deskew_flags(LioDeskewParams P, unsigne
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
         s_cnt[wave] = __popcll(m);
-        if (m) atomicMin(first_idx, blockIdx.x * 256 + wave * 64 + (__ffsll((long long)m) - 1));
+        // (one address for the whole sweep: 1 800 same-address atomics cost ~18 us of this kernel's 23; a wave whose candidate
+        //  cannot lower the value it sees -- stale or not, the minimum only falls -- skips the atomic: a few dozen remain)
+        if (m) {
+            const int cand = blockIdx.x * 256 + wave * 64 + (__ffsll((long long)m) - 1);
+            if (cand < __hip_atomic_load(first_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(first_idx, cand);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) blk_count[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
@@ -287,7 +292,8 @@ __global__ __launch_bounds__(256) void k_ri_first(LioRangeImageParams P, int* __
     const int cell = lio_ri_cell(P, f[0], f[1], f[2], lio_rec_ring(P.d, rec), range);
     if (cell < 0) return;
     atomicMin(&cell_first[cell], i);
-    atomicMin(first_idx, i);
+    // (same-address atomic of every point of the sweep: skipped when it cannot lower the value this lane sees)
+    if (i < __hip_atomic_load(first_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(first_idx, i);
 }
 
 // pass 2: one thread per cell: deskew the winner, write it at its rank among the occupied cells (ring-major,

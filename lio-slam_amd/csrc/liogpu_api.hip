@@ -381,6 +381,26 @@ extern "C" void* lio_host_alloc(size_t bytes)
     return p;
 }
 extern "C" void lio_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+// Device memory for callers that keep their clouds in HBM between calls (every entry point that takes `scans` / `data`
+// reads memory of the handle's own device in place).
+extern "C" void* lio_device_alloc(int32_t device_id, size_t bytes)
+{
+    void* p = nullptr;
+    if (hipSetDevice(device_id) != hipSuccess || hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void lio_device_free(int32_t device_id, void* p)
+{
+    if (p && hipSetDevice(device_id) == hipSuccess) (void)hipFree(p);
+}
+extern "C" int lio_device_upload(int32_t device_id, void* dst, const void* src, size_t bytes)
+{
+    if (!dst || (!src && bytes)) return lio_fail(LIO_ERR_ARG, "null pointer");
+    HIPCHK(hipSetDevice(device_id));
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return LIO_OK;
+}
 extern "C" int lio_host_register(void* p, size_t bytes)
 {
     if (!p || !bytes) return lio_fail(LIO_ERR_ARG, "null range");

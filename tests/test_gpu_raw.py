@@ -66,11 +66,6 @@ def test_downsample_and_register_is_one_device_chain(pkg, oracle, synth, small_c
 
 def test_chain_from_a_cloud_that_already_lives_on_the_device(pkg, synth, small_case):
     """cloud_deskewed produced on the device (lio_deskew output kept in HBM): the blob is read in place, no H2D at all."""
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")                         # the runtime libliogpu.so itself is linked against (already loaded)
-    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    hip.hipFree.argtypes = [C.c_void_p]
     sc, pose = _raw_sweep(synth, seed=302, k=2)
     guess = (pose + np.array([0.0, 0.002, -0.01, 0.05, 0.06, -0.02])).astype(np.float32)
     rec = _pcl(sc["xyz"], sc["intensity"])
@@ -78,11 +73,9 @@ def test_chain_from_a_cloud_that_already_lives_on_the_device(pkg, synth, small_c
     a = pkg.ScanToMap(); a.set_map(small_case["map"])
     b = pkg.ScanToMap(); b.set_map(small_case["map"])
     pa, ra, _, da = a.downsampleAndScan2MapOptimization(rec, len(rec), lay, 0.4, guess, want_ds=True)
-    dev = C.c_void_p()
-    assert hip.hipMalloc(C.byref(dev), rec.nbytes) == 0
-    assert hip.hipMemcpy(dev, rec.ctypes.data, rec.nbytes, 1) == 0          # hipMemcpyHostToDevice (synchronous)
-    pb, rb, _, db = b.downsampleAndScan2MapOptimization(None, len(rec), lay, 0.4, guess, want_ds=True, device_ptr=dev.value)
-    assert hip.hipFree(dev) == 0
+    dev = pkg.DeviceBuffer(rec)                                       # (the library's own runtime: no second HIP runtime in the process)
+    pb, rb, _, db = b.downsampleAndScan2MapOptimization(None, len(rec), lay, 0.4, guess, want_ds=True, device_ptr=dev.ptr)
+    dev.close()
     np.testing.assert_array_equal(pa, pb)
     np.testing.assert_array_equal(da.view(np.uint32), db.view(np.uint32))
     assert ra.iters == rb.iters

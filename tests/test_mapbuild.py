@@ -63,8 +63,11 @@ def test_oracle_transform_point_cloud(oracle, synth):
 
 # -------------------------------------------------------------------- GPU parity
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,leaf", [(1, 0.4), (63, 0.4), (5000, 0.4), (60000, 0.2), (60000, 2.0), (3000, 25.0)])
-def test_gpu_voxel_grid_bit_exact(pkg, oracle, n, leaf):
+@pytest.mark.parametrize("form", ["count", "sort"])
+@pytest.mark.parametrize("n,leaf", [(1, 0.4), (63, 0.4), (5000, 0.4), (60000, 0.2), (60000, 2.0), (3000, 25.0), (300000, 0.3)])
+def test_gpu_voxel_grid_bit_exact(pkg, oracle, n, leaf, form, monkeypatch):
+    """Both forms of K7 (counting sort over the key space; stable radix sort of (key, index) pairs, lio_voxsort.h)."""
+    monkeypatch.setenv("LIO_VOX_FORM", form)
     pts = _cloud(np.random.default_rng(n), n)
     out_g, rc_g = pkg.voxel_grid(pts, leaf)
     out_o, rc_o = oracle.voxel_grid(pts, leaf)
@@ -73,7 +76,23 @@ def test_gpu_voxel_grid_bit_exact(pkg, oracle, n, leaf):
 
 
 @pytest.mark.gpu
-def test_gpu_voxel_grid_edge_cases(pkg, oracle):
+def test_gpu_voxel_grid_key_spaces_beyond_the_counting_sort(pkg, oracle):
+    """A raw sweep at the reference's small scan leaves spans 10^8..10^9 voxels (mappingSurfLeafSize 0.2 / 0.15, jeep.yaml:99,
+    lio_sam_livox.yaml:56): the automatic choice sorts instead of keeping arrays over the key space, and everything PCL
+    filters (up to 2^31 - 1 voxels) is filtered -- the counting sort used to refuse more than 2^29."""
+    rng = np.random.default_rng(17)
+    pts = _cloud(rng, 120000, extent=(100, 100, 12))
+    for leaf in (0.2, 0.15, 0.09):                                   # 1.2e8, 2.8e8 and 1.3e9 voxels
+        out_g, rc_g = pkg.voxel_grid(pts, leaf)
+        out_o, rc_o = oracle.voxel_grid(pts, leaf)
+        assert rc_g == rc_o == 0 and len(out_g) == len(out_o) > 50000
+        np.testing.assert_array_equal(out_g.view(np.uint32), out_o.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["count", "sort"])
+def test_gpu_voxel_grid_edge_cases(pkg, oracle, form, monkeypatch):
+    monkeypatch.setenv("LIO_VOX_FORM", form)
     rng = np.random.default_rng(3)
     # many points in very few voxels (> 512 per voxel: the oversized-voxel path)
     dense = (_cloud(rng, 5000, extent=(0.3, 0.3, 0.1)))
