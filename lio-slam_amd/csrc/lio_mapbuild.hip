@@ -174,151 +174,6 @@ __global__ __launch_bounds__(256) void k_bbox_reduce(const float* __restrict__ b
 
 struct LioVoxGrid { float inv; int min_b0, min_b1, min_b2, mul1, mul2, n_keys; };
 
-// voxel index of pcl::VoxelGrid: x-fastest over the cloud's own bounding box
-// key_of[i] = voxel of point i, slot_of[i] = its arrival number inside the voxel (the value the counting atomic returns):
-// with the exclusive scan of the counts that is the point's place in the voxel-sorted index list, so the scatter needs no
-// second round of atomics (the order inside a voxel is arbitrary here; the centroid kernels sort by input index).
-__global__ void k_vox_keys(LioVoxGrid g, const float4* __restrict__ p, int n, int* __restrict__ key_of,
-                           int* __restrict__ slot_of, int* __restrict__ count)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 v = p[i];
-    const int i0 = (int)(floorf(v.x * g.inv) - (float)g.min_b0);
-    const int i1 = (int)(floorf(v.y * g.inv) - (float)g.min_b1);
-    const int i2 = (int)(floorf(v.z * g.inv) - (float)g.min_b2);
-    const int key = i0 + i1 * g.mul1 + i2 * g.mul2;
-    key_of[i] = key;
-    slot_of[i] = atomicAdd(&count[key], 1);
-}
-
-__global__ void k_vox_scatter(const int* __restrict__ key_of, const int* __restrict__ slot_of, int n, const int* __restrict__ start,
-                              int* __restrict__ tmp)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    tmp[start[key_of[i]] + slot_of[i]] = i;
-}
-
-__global__ void k_vox_list(const int* __restrict__ start, const int* __restrict__ rank, int n_keys,
-                           int* __restrict__ list)
-{
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_keys && start[k + 1] > start[k]) list[rank[k]] = k;
-}
-
-// Order of a voxel's points = ascending input index (the order pcl::VoxelGrid's sorted index vector visits them in; the fp32
-// running sum depends on it).  The counting sort leaves a voxel's list in arrival order, so every POINT computes its place
-// in its voxel's list by counting the smaller indices there: one thread per point, contiguous cached reads, no LDS, no
-// divergent insertion sort -- 1.3 M threads instead of the 67 k of a thread-per-voxel sort (round 2: 55 us for that kernel
-// alone at one wave per SIMD; this one ~10 us).  Voxels above LIO_VOX_RANK_MAX points are left to k_vox_centroid_large.
-#define LIO_VOX_RANK_MAX 128 // voxels with at most this many points: k_vox_rank + one thread adds them up (k_vox_centroid_ordered)
-#define LIO_VOX_LARGE 4096   // above LIO_VOX_RANK_MAX: one workgroup per voxel (bitonic sort in LDS); beyond this a slow exact fallback
-__global__ __launch_bounds__(256) void k_vox_rank(const int* __restrict__ key_of, int n, const int* __restrict__ start,
-                                                  const int* __restrict__ tmp, int* __restrict__ order)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int key = key_of[i];
-    const int b = start[key], m = start[key + 1] - b;
-    if (m > LIO_VOX_RANK_MAX) return;
-    int r = 0;
-    for (int j = 0; j < m; ++j) r += (tmp[b + j] < i) ? 1 : 0;
-    order[b + r] = i;
-}
-
-// One thread per occupied voxel: add its points up in that order in fp32 and divide by the count (PCL's CentroidPoint
-// accumulators).  Output position = rank of the voxel (ascending voxel index).  Crowded voxels are queued.
-__global__ __launch_bounds__(256) void k_vox_centroid_ordered(const float4* __restrict__ p, const int* __restrict__ start,
-                                                              const int* __restrict__ list, int n_out, const int* __restrict__ order,
-                                                              float4* __restrict__ out, int* __restrict__ large_list, int* __restrict__ n_large)
-{
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= n_out) return;
-    const int key = list[o];
-    const int b = start[key], n = start[key + 1] - b;
-    if (n > LIO_VOX_RANK_MAX) { large_list[atomicAdd(n_large, 1)] = o; return; }
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
-    int j = 0;
-    for (; j + 4 <= n; j += 4) {                              // four gathers in flight, the additions stay in order
-        const float4 v0 = p[order[b + j]], v1 = p[order[b + j + 1]], v2 = p[order[b + j + 2]], v3 = p[order[b + j + 3]];
-        sx += v0.x; sy += v0.y; sz += v0.z; si += v0.w;
-        sx += v1.x; sy += v1.y; sz += v1.z; si += v1.w;
-        sx += v2.x; sy += v2.y; sz += v2.z; si += v2.w;
-        sx += v3.x; sy += v3.y; sz += v3.z; si += v3.w;
-    }
-    for (; j < n; ++j) { const float4 v = p[order[b + j]]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
-    const float cnt = (float)n;
-    out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
-}
-
-// Crowded voxels (the rings next to the sensor put hundreds of returns into one 0.4 m voxel): one workgroup
-// per voxel, taken from the queue filled by k_vox_centroid.  Point indices are sorted with a bitonic network
-// in LDS, the points gathered in that order, and FOUR lanes add them up, one per component (x, y, z, intensity are four
-// independent running sums; the order inside each is the contract): a 4 000-point voxel is a chain of 4 000 dependent
-// additions per component whichever way it is cut, but one lane carrying all four chains ran them back to back.
-// The queue order is arbitrary; every voxel writes its own output slot.
-__global__ __launch_bounds__(256) void k_vox_centroid_large(const float4* __restrict__ p, const int* __restrict__ start,
-                                                            const int* __restrict__ list, const int* __restrict__ tmp,
-                                                            float4* __restrict__ out, const int* __restrict__ large_list,
-                                                            const int* __restrict__ n_large)
-{
-    __shared__ int s_idx[LIO_VOX_LARGE];
-    __shared__ __attribute__((aligned(16))) float4 s_pt[1024];
-    const int total = *n_large;
-    for (int q = blockIdx.x; q < total; q += gridDim.x) {
-        const int o = large_list[q];
-        const int key = list[o];
-        const int b = start[key], n = start[key + 1] - b;
-        float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
-        float acc = 0.0f;                                    // lanes 0..3: the running sum of component threadIdx.x
-        if (n <= LIO_VOX_LARGE) {
-            int np = 2;
-            while (np < n) np <<= 1;
-            for (int j = threadIdx.x; j < np; j += 256) s_idx[j] = j < n ? tmp[b + j] : 0x7fffffff;
-            __syncthreads();
-            for (int k = 2; k <= np; k <<= 1)
-                for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                    for (int t = threadIdx.x; t < (np >> 1); t += 256) {
-                        const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), pr = i | jj;
-                        const bool up = (i & k) == 0;
-                        const int x = s_idx[i], y = s_idx[pr];
-                        if ((x > y) == up) { s_idx[i] = y; s_idx[pr] = x; }
-                    }
-                    __syncthreads();
-                }
-            for (int c0 = 0; c0 < n; c0 += 1024) {           // gather a chunk in sorted order, then add it up
-                const int m = min(1024, n - c0);
-                for (int j = threadIdx.x; j < m; j += 256) s_pt[j] = p[s_idx[c0 + j]];
-                __syncthreads();
-                if (threadIdx.x < 4) {
-                    const float* comp = reinterpret_cast<const float*>(s_pt) + threadIdx.x;
-                    for (int j = 0; j < m; ++j) acc += comp[j * 4];
-                }
-                __syncthreads();
-            }
-            if (threadIdx.x < 4) reinterpret_cast<float*>(out + o)[threadIdx.x] = acc / (float)n;
-        } else if (threadIdx.x < 64) {
-            // more than 4096 points in one voxel: repeatedly pick the smallest input index above the previous one
-            const int lane = threadIdx.x;
-            int prev = -1;
-            for (int j = 0; j < n; ++j) {
-                int best = 0x7fffffff;
-                for (int i = lane; i < n; i += 64) { const int v = tmp[b + i]; if (v > prev && v < best) best = v; }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off));
-                prev = best;
-                if (lane == 0) { const float4 v = p[best]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
-            }
-        }
-        if (threadIdx.x == 0 && n > LIO_VOX_LARGE) {
-            const float cnt = (float)n;
-            out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
-        }
-        __syncthreads();
-    }
-}
-
 __global__ void k_xyzi4_to_aos(const float4* __restrict__ src, int n, unsigned char* __restrict__ dst, size_t stride)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -356,8 +211,7 @@ struct LioKeep {
 namespace {
 typedef LioTemp Buf;         // temporaries come from the recycling pool (lio_pool.h)
 
-template <class B> struct LioVoxWs { B bbox, key_of, slot_of, count, start, rank, tiles, tmp, list, large,
-                                     pairs_a, pairs_b, hist, blk_heads, seg_start, d_no, row_total; };   // (second row: the sorting form, lio_voxsort.h)
+template <class B> struct LioVoxWs { B bbox, large, pairs_a, pairs_b, hist, blk_heads, seg_start, d_no, row_total; };
 
 float ord2f(unsigned u)
 {
@@ -367,20 +221,11 @@ float ord2f(unsigned u)
     return f;
 }
 
-// Which form of K7 runs (results are bit-identical): the counting sort keeps arrays over the whole key space, the sorting form
-// (lio_voxsort.h) only over the points.  Auto: sort once the bounding box spans more than 4 M voxels -- a raw 100 m sweep at any
-// of the reference's scan leaves; the local map at leaf 0.5 m (~1 M voxels, 1.3 M points) stays with the counting sort, which is
-// faster there.  LIO_VOX_FORM=count|sort in the environment forces one (tests, A/B).
-static int lio_vox_form(long long n_keys)
-{
-    const char* e = getenv("LIO_VOX_FORM");                  // (read per call: the tests flip it)
-    const int forced = !e ? 0 : (!strcmp(e, "sort") ? 2 : (!strcmp(e, "count") ? 1 : 0));
-    if (forced == 2 || (forced == 1 && n_keys <= (1LL << 29))) return forced;
-    return n_keys > (4LL << 20) ? 2 : 1;
-}
-
-// The sorting form: keys -> stable LSD radix sort of (key, index) pairs -> segment heads -> in-order sums.  g describes the
-// voxel grid, n_keys its size (< 2^31).  `out` is allocated for the worst case (n voxels) so that the centroid kernels are
+// K7 proper (lio_voxsort.h): keys -> stable LSD radix sort of (key, index) pairs -> segment heads -> in-order sums.  g describes
+// the voxel grid, n_keys its size (< 2^31).  (Rounds 1-2 used a counting sort with count / start / rank arrays over the whole
+// key space, atomics for the slots and a per-voxel sort for the order; round 3 first replaced the per-voxel sorts, then measured
+// the sorting form faster on every input -- map assembly 0.37 against 0.43 ms, the raw-sweep chain 0.50 against 0.57 ms at leaf
+// 0.4 m and 0.88 against 1.09 ms at 0.15 m, profiles/r03_k7_forms.txt -- and removed the counting form.)  `out` is allocated for the worst case (n voxels) so that the centroid kernels are
 // enqueued without waiting for the count; the one host wait (*n_out) comes last and overlaps them.
 template <class B>
 static int voxel_grid_sorted(const float4* d_in, int n, const LioVoxGrid& g, long long n_keys, B& out, int* n_out, hipStream_t s, LioVoxWs<B>& ws)
@@ -475,52 +320,9 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out,
     g.mul1 = d0; g.mul2 = d0 * d1;
     const long long n_keys_ll = (long long)d0 * d1 * d2;
     if (n_keys_ll > 2147483647LL) return lio_fail_ext(LIO_ERR_CAPACITY, "voxel grid has more than 2^31 - 1 voxels", hipSuccess);
-    if (lio_vox_form(n_keys_ll) == 2) {
-        g.n_keys = 0;
-        return voxel_grid_sorted<B>(d_in, n, g, n_keys_ll, out, n_out, s, ws);
-    }
-    if (n_keys_ll > (1LL << 29)) return lio_fail_ext(LIO_ERR_CAPACITY, "voxel grid has more than 2^29 voxels", hipSuccess);
-    g.n_keys = (int)n_keys_ll;
-    B &key_of = ws.key_of, &slot_of = ws.slot_of, &count = ws.count, &start = ws.start, &rank = ws.rank, &tiles = ws.tiles, &tmp = ws.tmp, &list = ws.list;
-    HIPCHK(key_of.alloc(sizeof(int) * (size_t)n));
-    HIPCHK(slot_of.alloc(sizeof(int) * (size_t)n));
-    HIPCHK(tmp.alloc(sizeof(int) * (size_t)n));
-    HIPCHK(count.alloc(sizeof(int) * (size_t)g.n_keys));
-    HIPCHK(start.alloc(sizeof(int) * ((size_t)g.n_keys + 1)));
-    HIPCHK(rank.alloc(sizeof(int) * ((size_t)g.n_keys + 1)));
-    const int n_tiles = (g.n_keys + LIO_S2_TILE - 1) / LIO_S2_TILE;
-    HIPCHK(tiles.alloc(sizeof(unsigned long long) * ((size_t)n_tiles + 1)));
-    const int nb = (n + 255) / 256, nk = (g.n_keys + 255) / 256;
-    HIPCHK(hipMemsetAsync(count.p, 0, sizeof(int) * (size_t)g.n_keys, s));
-    hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, g, d_in, n, key_of.template as<int>(), slot_of.template as<int>(), count.template as<int>());
-    // start (first point of every voxel) and rank (output slot of every occupied voxel) in one pass over the counts
-    lio_launch_scan2<true>(count.template as<int>(), nullptr, g.n_keys, tiles.template as<unsigned long long>(),
-                           start.template as<int>(), rank.template as<int>(), s);
-    int no = 0;
-    HIPCHK(hipMemcpyAsync(&no, rank.template as<int>() + g.n_keys, sizeof(int), hipMemcpyDeviceToHost, s));
-    // (the scatter does not need the count: it runs while the host waits for it)
-    hipLaunchKernelGGL(k_vox_scatter, dim3(nb), dim3(256), 0, s, key_of.template as<int>(), slot_of.template as<int>(), n, start.template as<int>(), tmp.template as<int>());
-    // every point's place in its voxel's list in ascending input index; slot_of has been consumed by the scatter and becomes
-    // that ordered list.  Needs nothing the host is waiting for, so it runs under the wait as well.
-    hipLaunchKernelGGL(k_vox_rank, dim3(nb), dim3(256), 0, s, key_of.template as<int>(), n, start.template as<int>(), tmp.template as<int>(),
-                       slot_of.template as<int>());
-    HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(list.alloc(sizeof(int) * (size_t)(no ? no : 1)));
-    HIPCHK(out.alloc(sizeof(float4) * (size_t)(no ? no : 1)));
-    B& large = ws.large;                                     // [0] = count, [1..] = output slots of crowded voxels
-    HIPCHK(large.alloc(sizeof(int) * ((size_t)no + 1)));
-    HIPCHK(hipMemsetAsync(large.p, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_vox_list, dim3(nk), dim3(256), 0, s, start.template as<int>(), rank.template as<int>(), g.n_keys, list.template as<int>());
-    if (no) {
-        hipLaunchKernelGGL(k_vox_centroid_ordered, dim3((no + 255) / 256), dim3(256), 0, s, d_in, start.template as<int>(), list.template as<int>(), no,
-                           slot_of.template as<int>(), out.template as<float4>(), large.template as<int>() + 1, large.template as<int>());
-        hipLaunchKernelGGL(k_vox_centroid_large, dim3(no < 1024 ? no : 1024), dim3(256), 0, s, d_in, start.template as<int>(), list.template as<int>(),
-                           tmp.template as<int>(), out.template as<float4>(), large.template as<int>() + 1, large.template as<int>());
-    }
-    if (wait) HIPCHK(hipStreamSynchronize(s));       // (pool temporaries are recycled when the caller returns)
-    HIPCHK(hipGetLastError());
-    *n_out = no;
-    return LIO_OK;
+    g.n_keys = 0;
+    (void)wait;                                  // (the sorting form always ends with the wait for the voxel count)
+    return voxel_grid_sorted<B>(d_in, n, g, n_keys_ll, out, n_out, s, ws);
 }
 
 int voxel_grid_device(const float4* d_in, int n, float leaf, Buf& out, int* n_out, hipStream_t s)
@@ -610,8 +412,7 @@ extern "C" void lio_kf_store_destroy(lio_kf_store* s)
     (void)hipSetDevice(s->device_id);
     (void)hipDeviceSynchronize();
     if (s->d_pts) (void)hipFree(s->d_pts);
-    LioKeep* keep[] = { &s->vws.bbox, &s->vws.key_of, &s->vws.slot_of, &s->vws.count, &s->vws.start, &s->vws.rank, &s->vws.tiles, &s->vws.tmp, &s->vws.list,
-                        &s->vws.large, &s->vws.pairs_a, &s->vws.pairs_b, &s->vws.hist, &s->vws.blk_heads, &s->vws.seg_start, &s->vws.d_no, &s->vws.row_total,
+    LioKeep* keep[] = { &s->vws.bbox, &s->vws.large, &s->vws.pairs_a, &s->vws.pairs_b, &s->vws.hist, &s->vws.blk_heads, &s->vws.seg_start, &s->vws.d_no, &s->vws.row_total,
                         &s->world, &s->ds, &s->d_kf, &s->d_poses, &s->d_chunks, &s->blk_box };
     for (LioKeep* k : keep) k->release();
     delete s;
@@ -832,8 +633,7 @@ struct LioRawWs {
 void lio_raw_ws_free(LioRawWs* w)
 {
     if (!w) return;
-    LioKeep* keep[] = { &w->raw, &w->xyzi, &w->ds, &w->vws.bbox, &w->vws.key_of, &w->vws.slot_of, &w->vws.count, &w->vws.start, &w->vws.rank,
-                        &w->vws.tiles, &w->vws.tmp, &w->vws.list, &w->vws.large, &w->vws.pairs_a, &w->vws.pairs_b, &w->vws.hist,
+    LioKeep* keep[] = { &w->raw, &w->xyzi, &w->ds, &w->vws.bbox, &w->vws.large, &w->vws.pairs_a, &w->vws.pairs_b, &w->vws.hist,
                         &w->vws.blk_heads, &w->vws.seg_start, &w->vws.d_no, &w->vws.row_total };
     for (LioKeep* k : keep) k->release();
     delete w;
