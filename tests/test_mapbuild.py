@@ -63,11 +63,9 @@ def test_oracle_transform_point_cloud(oracle, synth):
 
 # -------------------------------------------------------------------- GPU parity
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["count", "sort"])
-@pytest.mark.parametrize("n,leaf", [(1, 0.4), (63, 0.4), (5000, 0.4), (60000, 0.2), (60000, 2.0), (3000, 25.0), (300000, 0.3)])
-def test_gpu_voxel_grid_bit_exact(pkg, oracle, n, leaf, form, monkeypatch):
-    """Both forms of K7 (counting sort over the key space; stable radix sort of (key, index) pairs, lio_voxsort.h)."""
-    monkeypatch.setenv("LIO_VOX_FORM", form)
+@pytest.mark.parametrize("n,leaf", [(1, 0.4), (63, 0.4), (5000, 0.4), (60000, 0.2), (60000, 2.0), (3000, 25.0), (300000, 0.3), (1100000, 0.5)])
+def test_gpu_voxel_grid_bit_exact(pkg, oracle, n, leaf):
+    """K7: stable radix sort of (voxel key, input index) pairs + in-order sums (lio_voxsort.h), 1 point .. 1.1 M points (both tile sizes)."""
     pts = _cloud(np.random.default_rng(n), n)
     out_g, rc_g = pkg.voxel_grid(pts, leaf)
     out_o, rc_o = oracle.voxel_grid(pts, leaf)
@@ -78,8 +76,8 @@ def test_gpu_voxel_grid_bit_exact(pkg, oracle, n, leaf, form, monkeypatch):
 @pytest.mark.gpu
 def test_gpu_voxel_grid_key_spaces_beyond_the_counting_sort(pkg, oracle):
     """A raw sweep at the reference's small scan leaves spans 10^8..10^9 voxels (mappingSurfLeafSize 0.2 / 0.15, jeep.yaml:99,
-    lio_sam_livox.yaml:56): the automatic choice sorts instead of keeping arrays over the key space, and everything PCL
-    filters (up to 2^31 - 1 voxels) is filtered -- the counting sort used to refuse more than 2^29."""
+    lio_sam_livox.yaml:56): K7 sorts the points instead of keeping arrays over the key space, so everything PCL filters (up
+    to 2^31 - 1 voxels) is filtered -- the counting sort of rounds 1-2 refused more than 2^29 and memset gigabytes below that."""
     rng = np.random.default_rng(17)
     pts = _cloud(rng, 120000, extent=(100, 100, 12))
     for leaf in (0.2, 0.15, 0.09):                                   # 1.2e8, 2.8e8 and 1.3e9 voxels
@@ -90,9 +88,7 @@ def test_gpu_voxel_grid_key_spaces_beyond_the_counting_sort(pkg, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["count", "sort"])
-def test_gpu_voxel_grid_edge_cases(pkg, oracle, form, monkeypatch):
-    monkeypatch.setenv("LIO_VOX_FORM", form)
+def test_gpu_voxel_grid_edge_cases(pkg, oracle):
     rng = np.random.default_rng(3)
     # many points in very few voxels (> 512 per voxel: the oversized-voxel path)
     dense = (_cloud(rng, 5000, extent=(0.3, 0.3, 0.1)))
@@ -100,8 +96,8 @@ def test_gpu_voxel_grid_edge_cases(pkg, oracle, form, monkeypatch):
     out_o, _ = oracle.voxel_grid(dense, 0.5)
     np.testing.assert_array_equal(out_g.view(np.uint32), out_o.view(np.uint32))
     assert len(out_g) <= 8
-    # every tier of the centroid pass in one cloud: voxels with 1..32 points (one thread each), 33..128 (one
-    # wave), 129..4096 (one workgroup, bitonic sort) and > 4096 (exact fallback)
+    # both tiers of the centroid pass in one cloud: voxels with 1..128 points (one thread each) and crowded ones
+    # (one workgroup, 1024 points at a time through LDS, four component lanes)
     tiers = [_cloud(rng, 40000, extent=(20, 20, 2))]
     for k, cnt in enumerate((60, 128, 129, 700, 4096, 4097, 9000)):
         blob = _cloud(rng, cnt, extent=(0.3, 0.3, 0.3))
