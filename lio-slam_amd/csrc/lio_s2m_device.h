@@ -15,6 +15,9 @@
                               // same occupancy (0.144 vs 0.131 ms/launch) -- the loop is bound by the 64 B/clk L1 delivery of
                               // 1 KiB per wave-wide 16-byte load, not by latency; more loads in flight only queue up.
 #endif
+#ifndef LIO_ARRIVE_ACQREL
+#define LIO_ARRIVE_ACQREL 0
+#endif
 #define LIO_IDX_MASK 0x1fffffff      // index carried by the dummy records that pad the neighbourhood rows (never a winner)
 
 // ------------------------------------------------------------------ helpers
@@ -370,10 +373,18 @@ LIO_DEV void lio_arrive_and_finish(const LioIterParams& P, const LioBlockDesc& b
     // sums have left the wave's vector-memory queue -- they are complete at the agent-coherent level -- before the arrival
     // below can be observed by another workgroup.  An agent-scope release fence would order them too, but it writes back the
     // whole L2 of the XCD; the stores are sc1 precisely so that this counter wait is all that is needed.
+#if !LIO_ARRIVE_ACQREL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     int last = 0;
     if (lane == 0) {
+#if LIO_ARRIVE_ACQREL
+        // A/B variant (make EXTRA=-DLIO_ARRIVE_ACQREL=1): the same protocol in the language's terms -- an acquire-release RMW at
+        // agent scope instead of the hand-placed wait.  Measured in round 3; the default stays the wait.
+        const unsigned old = __hip_atomic_fetch_add(&P.arrive[bd.scan], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
         const unsigned old = atomicAdd(&P.arrive[bd.scan], 1u);
+#endif
         last = (old == (unsigned)bd.n_blk - 1u);
     }
     last = __shfl(last, 0);
