@@ -267,8 +267,8 @@ static int voxel_grid_sorted(const float4* d_in, int n, const LioVoxGrid& g, lon
     hipLaunchKernelGGL(k_vsort_head_emit, dim3(n_hblk), dim3(256), 0, s, a, n, ws.blk_heads.template as<int>(), d_no, ws.seg_start.template as<int>());
     int no = 0;
     HIPCHK(hipMemcpyAsync(&no, d_no, sizeof(int), hipMemcpyDeviceToHost, s));
-    hipLaunchKernelGGL(k_vsort_centroid, dim3((n + 255) / 256), dim3(256), 0, s, d_in, a, ws.seg_start.template as<int>(), d_no,
-                       out.template as<float4>(), ws.large.template as<int>(), d_no + 1);
+    hipLaunchKernelGGL(k_vsort_centroid, dim3((n_hblk + 3) / 4), dim3(256), 0, s, d_in, a, n, ws.seg_start.template as<int>(),
+                       ws.blk_heads.template as<int>(), n_hblk, d_no, out.template as<float4>(), ws.large.template as<int>(), d_no + 1);
     hipLaunchKernelGGL(k_vsort_centroid_large, dim3(n < 1024 * 64 ? (n + 63) / 64 : 1024), dim3(256), 0, s, d_in, a, ws.seg_start.template as<int>(),
                        out.template as<float4>(), ws.large.template as<int>(), d_no + 1);
     HIPCHK(hipStreamSynchronize(s));                                              // (`no`; the centroid kernels ran under this wait)

@@ -223,59 +223,58 @@ __global__ __launch_bounds__(256) void k_vsort_head_emit(const uint2* __restrict
 
 #define LIO_VS_SERIAL_MAX 128    // voxels with at most this many points: one thread adds them up; larger ones are queued
 
-// One thread per voxel: the fp32 running sums of its points in ascending input index (the order they sit in after the stable
-// sort), divided by the count (PCL's CentroidPoint accumulators).  A wave's 64 voxels own ONE contiguous stretch of the sorted
-// pairs: the wave first gathers that stretch's points into LDS with all lanes (independent loads, fully in flight), then
-// every lane adds its own voxel up from LDS -- the additions are a serial chain by contract, the loads need not be (a first
-// version let every thread chase sorted[j] -> p[...] itself: 42 us for 67 k voxels at one wave per SIMD).  Stretches above
-// LIO_VS_WAVE_CAP points (a crowded voxel among the 64) fall back to per-thread gathers.  *n_seg is read on the device: the
-// grid is sized for the worst case so that nothing has to wait for the host to learn the number of voxels.
-#define LIO_VS_WAVE_CAP 1024
-__global__ __launch_bounds__(256) void k_vsort_centroid(const float4* __restrict__ p, const uint2* __restrict__ sorted,
-                                                        const int* __restrict__ seg_start, const int* __restrict__ n_seg,
-                                                        float4* __restrict__ out, int* __restrict__ large_list, int* __restrict__ n_large)
+// The fp32 running sums of every voxel's points in ascending input index (the order they sit in after the stable sort),
+// divided by the count (PCL's CentroidPoint accumulators).  Work is cut by POINTS, not by voxels: wave-chunk c owns the voxels
+// whose head lies in the 1024 sorted positions [1024 c, 1024 (c + 1)) -- blk_heads[c] .. blk_heads[c + 1], the same blocking
+// the head count used -- gathers positions [1024 c, 1024 (c + 1) + LIO_VS_SERIAL_MAX) into LDS with all lanes (index loads,
+// then point gathers, all independent), and then every lane adds its voxels up from LDS.  The additions are a serial chain
+// by contract; the loads need not be.  (Two earlier forms: one thread per voxel chasing sorted[j] -> p[...] itself, 42 us for
+// 67 k voxels at one wave per SIMD; 32 voxels per wave staged when they fit -- the local map's busiest voxels hold ~100
+// points each, so the chunks that matter never fitted and one lane chasing 100 points set the kernel's time, 45 us.)
+// Voxels above LIO_VS_SERIAL_MAX points go to k_vsort_centroid_large.  Nothing here needs the host to know the voxel count.
+#define LIO_VS_CHUNK 1024
+__global__ __launch_bounds__(256) void k_vsort_centroid(const float4* __restrict__ p, const uint2* __restrict__ sorted, int n,
+                                                        const int* __restrict__ seg_start, const int* __restrict__ blk_heads, int n_hblk,
+                                                        const int* __restrict__ n_seg, float4* __restrict__ out,
+                                                        int* __restrict__ large_list, int* __restrict__ n_large)
 {
-    __shared__ __attribute__((aligned(16))) float4 s_pt[4][LIO_VS_WAVE_CAP];
-    const int ns = *n_seg;
+    __shared__ __attribute__((aligned(16))) float4 s_pt[4][LIO_VS_CHUNK + LIO_VS_SERIAL_MAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int o0 = blockIdx.x * 256 + wave * 64;             // first voxel of this wave
-    if (o0 >= ns) return;                                    // wave-uniform
-    const int o = o0 + lane;
-    const int w_b = seg_start[o0], w_e = seg_start[min(o0 + 64, ns)];
-    const int b = o < ns ? seg_start[o] : w_e, n = o < ns ? seg_start[o + 1] - b : 0;
-    const bool staged = (w_e - w_b) <= LIO_VS_WAVE_CAP;      // wave-uniform
-    if (staged) {
-        for (int i = lane; i < w_e - w_b; i += 64) s_pt[wave][i] = p[sorted[w_b + i].y];
+    const int c = blockIdx.x * 4 + wave;                     // this wave's chunk
+    if (c >= n_hblk) return;                                 // wave-uniform
+    const int o_lo = blk_heads[c], o_hi = c + 1 < n_hblk ? blk_heads[c + 1] : *n_seg;
+    if (o_lo >= o_hi) return;                                // no voxel starts here (the inside of a crowded voxel)
+    const int base = c * LIO_VS_CHUNK, m = min(n - base, LIO_VS_CHUNK + LIO_VS_SERIAL_MAX);
+    {   // stage: 18 index loads, then 18 point gathers, then the LDS writes
+        constexpr int R = (LIO_VS_CHUNK + LIO_VS_SERIAL_MAX) / 64;
+        unsigned idx[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) idx[k] = (k * 64 + lane < m) ? sorted[base + k * 64 + lane].y : 0u;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const float4 v = p[idx[k]];
+            if (k * 64 + lane < m) s_pt[wave][k * 64 + lane] = v;
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // one wave: its LDS writes are complete before its lanes read them
         __builtin_amdgcn_wave_barrier();
     }
-    if (o >= ns) return;
-    if (n > LIO_VS_SERIAL_MAX) { large_list[atomicAdd(n_large, 1)] = o; return; }
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
-    if (staged) {
-        const float4* q = &s_pt[wave][b - w_b];
+    for (int o = o_lo + lane; o < o_hi; o += 64) {
+        const int b = seg_start[o], cnt_o = seg_start[o + 1] - b;
+        if (cnt_o > LIO_VS_SERIAL_MAX) { large_list[atomicAdd(n_large, 1)] = o; continue; }
+        const float4* q = &s_pt[wave][b - base];
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
         int j = 0;
-        for (; j + 4 <= n; j += 4) {                         // four LDS reads in flight, the additions stay in order
+        for (; j + 4 <= cnt_o; j += 4) {                     // four LDS reads in flight, the additions stay in order
             const float4 v0 = q[j], v1 = q[j + 1], v2 = q[j + 2], v3 = q[j + 3];
             sx += v0.x; sy += v0.y; sz += v0.z; si += v0.w;
             sx += v1.x; sy += v1.y; sz += v1.z; si += v1.w;
             sx += v2.x; sy += v2.y; sz += v2.z; si += v2.w;
             sx += v3.x; sy += v3.y; sz += v3.z; si += v3.w;
         }
-        for (; j < n; ++j) { const float4 v = q[j]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
-    } else {
-        int j = 0;
-        for (; j + 4 <= n; j += 4) {
-            const float4 v0 = p[sorted[b + j].y], v1 = p[sorted[b + j + 1].y], v2 = p[sorted[b + j + 2].y], v3 = p[sorted[b + j + 3].y];
-            sx += v0.x; sy += v0.y; sz += v0.z; si += v0.w;
-            sx += v1.x; sy += v1.y; sz += v1.z; si += v1.w;
-            sx += v2.x; sy += v2.y; sz += v2.z; si += v2.w;
-            sx += v3.x; sy += v3.y; sz += v3.z; si += v3.w;
-        }
-        for (; j < n; ++j) { const float4 v = p[sorted[b + j].y]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
+        for (; j < cnt_o; ++j) { const float4 v = q[j]; sx += v.x; sy += v.y; sz += v.z; si += v.w; }
+        const float cnt = (float)cnt_o;
+        out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
     }
-    const float cnt = (float)n;
-    out[o] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
 }
 
 // Crowded voxels (the rings next to the sensor put thousands of returns into one voxel): one workgroup per queued voxel
