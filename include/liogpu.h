@@ -88,8 +88,8 @@ typedef struct lio_s2m_config {
                                 search by the distances to its previous 5 neighbours (exact:
                                 the candidate run shrinks, the result does not change)      */
     int32_t pipeline;        /* how the Gauss-Newton loop MO:1848-1859 is issued; results are identical for every value.
-                                0 = auto: one launch per iteration (k_s2m_iterate), or -- for a batch of at most a quarter
-                                of a workgroup per compute unit, e.g. a lone registration, unless use_graph or profile = 2
+                                0 = auto: one launch per iteration (k_s2m_iterate), or -- for a batch of at most half
+                                a workgroup per compute unit, e.g. a lone registration, unless use_graph or profile = 2
                                 is set -- the whole loop as ONE launch (k_s2m_persist: per-scan barrier between
                                 iterations; 0.17 against 0.25 ms per registration on MI355X); 1 = always one launch per
                                 iteration; 4 = the one-launch loop for every batch of at most one workgroup per compute

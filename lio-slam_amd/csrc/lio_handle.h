@@ -53,7 +53,10 @@ struct lio_s2m_handle {
     float4* d_nbr_pts = nullptr; size_t cap_nbr_pts = 0;
     int* d_nbr_slot = nullptr;   size_t cap_nbr_slot = 0;      // [n_map][(2k+1)^2] place of every replica inside its row-cell list
     unsigned* d_bbox = nullptr;
-    unsigned char* d_stage = nullptr; size_t cap_stage = 0;
+    unsigned char* d_stage = nullptr; size_t cap_stage = 0;          // the resident batch's records as uploaded
+    unsigned char* d_map_stage = nullptr; size_t cap_map_stage = 0;  // lio_s2m_set_map's upload (its own buffer: the batch's staged
+                                                                     // records stay valid -- the one-launch loop and
+                                                                     // lio_kf_store_add_from_handle read them after a new map)
     LioGrid grid{};
 
     // ---- resident scan batch (laserCloudSurfLastDS, MO:138) ----

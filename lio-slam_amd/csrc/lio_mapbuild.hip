@@ -664,7 +664,10 @@ extern "C" int lio_s2m_register_raw(lio_s2m_handle* h, const void* data, size_t 
     const size_t step = layout->point_step, n = n_points;
     // the blob: read in place when it is device memory of this device, else one H2D copy (a true DMA when pinned)
     const unsigned char* d_rec = nullptr;
-    bool pinned = false;
+    struct PinGuard {                                    // hipHostRegister for the duration of the call, released on every path
+        void* p = nullptr;
+        ~PinGuard() { if (p) (void)hipHostUnregister(p); }
+    } pin;
     if (n) {
         hipPointerAttribute_t at;
         bool in_place = false;
@@ -674,7 +677,7 @@ extern "C" int lio_s2m_register_raw(lio_s2m_handle* h, const void* data, size_t 
             d_rec = (const unsigned char*)data;
         } else {
             if (layout->pin_host) {
-                pinned = hipHostRegister(const_cast<void*>(data), n * step, hipHostRegisterDefault) == hipSuccess;
+                if (hipHostRegister(const_cast<void*>(data), n * step, hipHostRegisterDefault) == hipSuccess) pin.p = const_cast<void*>(data);
                 (void)hipGetLastError();
             }
             HIPCHK(w->raw.alloc(n * step));
@@ -688,7 +691,6 @@ extern "C" int lio_s2m_register_raw(lio_s2m_handle* h, const void* data, size_t 
     int no = 0;
     // (the filter's first host wait -- the bounding box -- also covers the H2D copy: the caller's blob is free again)
     rc = voxel_grid_device<LioKeep>(w->xyzi.as<float4>(), (int)n, leaf, w->ds, &no, s, w->vws, false, nullptr);
-    if (pinned) (void)hipHostUnregister(const_cast<void*>(data));
     if (rc < 0) return rc;                               // (rc == 1: PCL would pass the cloud through -- and so did we)
     if (n == 0) HIPCHK(w->ds.alloc(sizeof(float4)));
     h->int_off = 12;                                     // the staged records are float4 (x, y, z, intensity)

@@ -142,7 +142,7 @@ extern "C" void lio_s2m_destroy(lio_s2m_handle* h)
     if (h->corner) { lio_s2m_destroy(h->corner); h->corner = nullptr; }
     if (h->raw_ws) { lio_raw_ws_free(h->raw_ws); h->raw_ws = nullptr; }
     void* ptrs[] = { h->d_mx, h->d_my, h->d_mz, h->d_map4, h->d_sorted, h->d_cell_of, h->d_cell_count,
-                     h->d_cell_start, h->d_tile_sums, h->d_bbox, h->d_stage, h->d_sx, h->d_sy, h->d_sz,
+                     h->d_cell_start, h->d_tile_sums, h->d_bbox, h->d_stage, h->d_map_stage, h->d_sx, h->d_sy, h->d_sz,
                      h->d_state, h->d_poses, h->d_blocks, h->d_partials, h->d_arrive, h->d_rec_flag,
                      h->d_rec_coeff, h->d_rec_nn, h->d_active, h->d_tiles, h->d_prep_blocks, h->d_key_of,
                      h->d_key_count, h->d_key_start, h->d_key_tiles, h->d_tmp_idx, h->d_perm, h->d_stamps, h->d_nbr_start, h->d_nbr_pts,
@@ -297,10 +297,10 @@ extern "C" int lio_s2m_set_map(lio_s2m_handle* h, const void* pts, size_t n, siz
     h->has_map = false;
     int rc = lio_map_reserve(h, n);
     if (rc != LIO_OK) return rc;
-    HIPCHK(lio_grow(&h->d_stage, &h->cap_stage, (n ? n : 1) * stride));
+    HIPCHK(lio_grow(&h->d_map_stage, &h->cap_map_stage, (n ? n : 1) * stride));
     if (n) {
-        HIPCHK(hipMemcpyAsync(h->d_stage, pts, n * stride, hipMemcpyHostToDevice, h->stream));
-        lio_launch_aos_to_soa(h->d_stage, stride, (int)n, h->d_mx, h->d_my, h->d_mz, h->d_map4, h->stream);
+        HIPCHK(hipMemcpyAsync(h->d_map_stage, pts, n * stride, hipMemcpyHostToDevice, h->stream));
+        lio_launch_aos_to_soa(h->d_map_stage, stride, (int)n, h->d_mx, h->d_my, h->d_mz, h->d_map4, h->stream);
     }
     return lio_map_finish(h, n, t0);
 }
@@ -471,15 +471,17 @@ extern "C" int lio_s2m_set_shard_plan(lio_s2m_handle* h, int32_t axis, int32_t n
 // The whole Gauss-Newton loop as one launch (k_s2m_persist, lio_persist.hip): possible when every workgroup of the batch is
 // resident at once and the batch uses nothing but the default surf association; measured faster than the launch loop
 // for every batch that fits (0.17 against 0.25 ms for a lone registration).  cfg.pipeline = 4 takes
-// it for up to one workgroup per compute unit; auto (0) for up to a quarter of that -- a lone registration is ~26
-// workgroups --, so that several handles doing so at the same time still fit the device together (a workgroup that waits
-// at its scan's barrier keeps its slot; the polls are bounded, a launch that cannot make progress ends with LIO_ERR_HIP).
+// it for up to one workgroup per compute unit; auto (0) for up to half of that -- a lone registration is ~26 workgroups
+// at the default 0.4 m scan leaf, 76 / 111 at the reference's 0.2 / 0.15 m leaves (6-8 % faster there than the launch loop,
+// profiles/r03_callback_leaf_sizes.txt) --, so that two handles doing so at the same time still fit the device together (a
+// workgroup that waits at its scan's barrier keeps its slot; the polls are bounded, and a launch that cannot make progress
+// is re-run through the launch loop inside lio_s2m_batch_results: a few milliseconds, never an error).
 // Auto steps aside for an explicit cfg.use_graph and for the diagnostic phase clock of the launch loop (cfg.profile = 2).
 static bool lio_persist_eligible(const lio_s2m_handle* h)
 {
     int limit = 0;
     if (h->cfg.pipeline == 4) limit = h->n_cu;
-    else if (h->cfg.pipeline == 0 && !h->cfg.use_graph && h->cfg.profile != 2) limit = h->n_cu / 4;
+    else if (h->cfg.pipeline == 0 && !h->cfg.use_graph && h->cfg.profile != 2) limit = h->n_cu / 2;
     return limit > 0 && !h->no_persist && !h->cfg.use_lds && h->ppt == 1 && h->shard.axis < 0 &&
            h->block_world == 1 && h->n_blocks > 0 && h->n_blocks + h->n_scans <= limit;      // (+ one helper workgroup per scan)
 }

@@ -285,3 +285,26 @@ def test_one_launch_loop_under_real_contention_falls_back_and_stays_right(pkg, s
         np.testing.assert_array_equal(p, want[k % len(qs)])
     assert fallbacks >= 1                                    # the contention was real: at least one launch timed out and was recovered
     owner.close()
+
+
+def test_a_new_map_leaves_the_staged_scan_alone(pkg, small_case):
+    """The one-launch loop reads the scan from the records as they were uploaded (no SoA copy is made for it), and
+    lio_kf_store_add_from_handle turns those records into a keyframe.  lio_s2m_set_map used to stage the MAP upload in the
+    same buffer: re-running a resident batch after a new map, or saving the keyframe after it, then read map bytes."""
+    q = small_case["queries"][0]
+    h = pkg.ScanToMap(pipeline=4)
+    h.set_map(small_case["map"])
+    p0, r0, _ = h.scan2MapOptimization(q["scan"], q["pose_init"])
+    h.set_map(small_case["map"][::-1].copy())                    # same points, new upload (a different caller order)
+    h.batch_set_poses(q["pose_init"][None, :]); h.batch_run()
+    p1, r1 = h.batch_results()
+    assert h.profile().pipeline == 4 and r1[0].iters == r0.iters
+    assert np.abs(p1[0] - p0).max() <= 1e-5                       # (the sums are added in the same order; neighbour indices differ)
+    store_a, store_b = pkg.KeyframeStore(), pkg.KeyframeStore()
+    ka = store_a.add_from_handle(h, 0)
+    kb = store_b.add(np.concatenate([q["scan"], np.zeros((len(q["scan"]), 1), np.float32)], 1))
+    ident = np.zeros((1, 6), np.float32)
+    a, _, _ = store_a.assemble([ka], ident, 0.3, want_output=True, max_out=len(q["scan"]) + 16)
+    b, _, _ = store_b.assemble([kb], ident, 0.3, want_output=True, max_out=len(q["scan"]) + 16)
+    np.testing.assert_array_equal(a[:, :3].view(np.uint32), b[:, :3].view(np.uint32))
+    store_a.close(); store_b.close(); h.close()

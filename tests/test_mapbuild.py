@@ -167,3 +167,23 @@ def test_gpu_assemble_map_matches_oracle_and_feeds_registration(pkg, oracle, syn
     with pytest.raises(pkg.LioError):
         store.assemble([99], poses2[:1], 0.5)
     store.close(); s2m.close(); ref.close()
+
+
+@pytest.mark.gpu
+def test_gpu_voxel_grid_fuzz(pkg, oracle):
+    """Seeded random clouds: sizes across both sort tiles (4 / 8 items per thread), leaves from a few centimetres to metres,
+    extents from one voxel to a 2^30-voxel box, clusters that crowd single voxels -- bit-exact against the oracle every time."""
+    rng = np.random.default_rng(20241022)
+    for trial in range(14):
+        n = int(rng.choice([1, 2, 65, 1000, 4097, 30000, 70000, 270000]))
+        ext = (float(rng.choice([0.05, 3.0, 40.0, 120.0])), float(rng.choice([0.05, 20.0, 120.0])), float(rng.choice([0.01, 4.0, 15.0])))
+        leaf = float(rng.choice([0.07, 0.15, 0.4, 1.3]))
+        pts = _cloud(rng, n, extent=ext)
+        if trial % 3 == 0 and n > 100:                       # a third of the points piled into a few spots
+            k = n // 3
+            pts[:k, :3] = pts[rng.integers(0, n, 4)][:, :3][rng.integers(0, 4, k)] + rng.normal(0, 0.02, (k, 3)).astype(np.float32)
+            pts = pts[rng.permutation(n)]
+        out_g, rc_g = pkg.voxel_grid(pts, leaf)
+        out_o, rc_o = oracle.voxel_grid(pts, leaf)
+        assert rc_g == rc_o and len(out_g) == len(out_o), (trial, n, ext, leaf)
+        np.testing.assert_array_equal(out_g.view(np.uint32), out_o.view(np.uint32), err_msg=str((trial, n, ext, leaf)))

@@ -15,7 +15,8 @@ case = synth.make_case("hdl64", n_keyframes=200, seed=synth.BASE_SEED, n_queries
                        scan_leaf=LEAF_S, map_leaf=LEAF_M)
 kc = [np.concatenate([c, np.zeros((len(c), 1), np.float32)], 1) for c, _ in case["keyframes"]]
 kp = np.stack([p for _, p in case["keyframes"]])
-node = pkg.ScanToMap()
+PIPE = int(sys.argv[3]) if len(sys.argv) > 3 else 0             # cfg.pipeline of the node's handle (0 = auto)
+node = pkg.ScanToMap(pipeline=PIPE)
 store = pkg.KeyframeStore()
 ids = [store.add(c) for c in kc]
 recs = []
