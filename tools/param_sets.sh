@@ -9,6 +9,8 @@
 #   dense    0.2 / 0.1, obstacle density 0.06: N_m >= 0.5 M, the 25x replicated rows (>= 200 MB) no longer fit L2 + Infinity Cache
 #   dense_k1 / dense_k3   the same with cfg.cell_div = 1 / 3 (9x / 49x replicated rows)
 #   long     1000 keyframes along a 1 km street with 6x the obstacles, default leaves: a LARGE map at the usual point spacing
+#   km3      3000 keyframes along a 3 km street, default leaves and obstacle density: N_m ~ 1 M at the USUAL point spacing, the
+#            25x rows (~400 MB) no longer fit the 256 MB Infinity Cache; km3_k1: the same with cell_div 1 (9x rows, ~150 MB)
 #   whatif   timing only (WRONG results by construction): the 5-NN gate shrunk to 0.8 m / 0.667 m, the upper bound of what a
 #            second, tighter row table could win once a search bound exists (next #5)
 set -u
@@ -53,6 +55,8 @@ for s in $SETS; do
     dense_k3) one dense_k3 --leaf-scan 0.2 --leaf-map 0.1 --density 0.06 --batch 128 --batches 2 --celldiv 3 ;;
     livox_k3) one livox_k3 --leaf-scan 0.15 --leaf-map 0.3 --batch 128 --batches 2 --celldiv 3 ;;
     long)    one long --keyframes 1000 --density 0.12 --batch 256 --batches 2 ;;
+    km3)     one km3 --keyframes 3000 --batch 256 --batches 2 ;;
+    km3_k1)  one km3_k1 --keyframes 3000 --batch 256 --batches 2 --celldiv 1 ;;
     long_k1) one long_k1 --keyframes 1000 --density 0.12 --batch 256 --batches 2 --celldiv 1 ;;
     whatif)  one whatif_gate0.8 --maxsq 0.64 ; one whatif_gate0.667 --maxsq 0.4444 ;;
     esac
