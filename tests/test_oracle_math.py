@@ -340,3 +340,22 @@ def test_eigen6_order_and_threshold_decisions_match_lapack_on_near_degenerate_ma
             matP = inv.astype(np.float64) @ v2.astype(np.float64)
             np.testing.assert_allclose(matP, P_ref, atol=5e-4)
     assert n_thr > 50
+
+
+def test_knn_matches_scikit_learn_kd_tree(oracle):
+    """A third implementation, sharing neither code nor author with the oracle or the device grid: scikit-learn's KDTree
+    (exact search) on a street-like cloud.  Index SETS must agree wherever the fifth and sixth distances are not a
+    rounding-level tie (sklearn computes in float64 and leaves tie order open); distances agree to fp32 rounding."""
+    from sklearn.neighbors import KDTree
+    rng = np.random.default_rng(99)
+    ground = np.c_[rng.uniform(-60, 60, 6000), rng.uniform(-12, 12, 6000), rng.normal(0, 0.01, 6000)]
+    wall = np.c_[rng.uniform(-60, 60, 4000), np.full(4000, 12.0) + rng.normal(0, 0.01, 4000), rng.uniform(0, 8, 4000)]
+    pts = np.concatenate([ground, wall]).astype(np.float32)
+    q = (pts[rng.integers(0, len(pts), 800)] + rng.normal(0, 0.15, (800, 3))).astype(np.float32)
+    idx, d2 = oracle.knn5(pts, q, "kdtree")
+    dist, ind = KDTree(pts.astype(np.float64), leaf_size=20).query(q.astype(np.float64), k=6)
+    clear = (dist[:, 5] - dist[:, 4]) > 1e-5 * np.maximum(dist[:, 4], 1e-3)
+    assert clear.sum() > 700
+    for j in np.nonzero(clear)[0]:
+        assert set(idx[j]) == set(ind[j, :5]), j
+    np.testing.assert_allclose(np.sqrt(d2[clear]), np.sort(dist[clear, :5], axis=1), rtol=2e-6, atol=2e-6)
