@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--shard", choices=["map", "scan"], default="map",
                     help="N>1: map = slabs of the map + halo, owner-computes (north_star); scan = map replicated, workgroups of every scan dealt round-robin")
     ap.add_argument("--nncache", type=int, default=1, help="1 = bound each point's search by its previous neighbours (exact)")
-    ap.add_argument("--pipeline", type=int, default=0, help="0/1 = fused k_s2m_iterate, 2 = split cert/scan/fit (A/B only)")
+    ap.add_argument("--pipeline", type=int, default=0, help="cfg.pipeline: 0 = auto, 1 = one launch per GN iteration, 4 = one-launch loop where it fits")
     ap.add_argument("--roofline-pass-only", action="store_true", help="profiling: make the roofline pass (GN loop alone on one "
                     "pre-sorted resident batch, launches of k_s2m_iterate never overlapping anything) the ONLY timed region")
     ap.add_argument("--single-buffer", action="store_true", help="A/B: one handle, no overlap of staging and GN loop")
@@ -573,7 +573,7 @@ def main():
             "single GPU" if not sharded else
             (f"map sharded x{world} (slabs + halo, owner-computes)" if args.shard == "map" else
              f"map replicated, scan workgroups dealt over {world} ranks") + " + RCCL all-reduce of JtJ/Jtr per GN iteration",
-            "kernel": {"points_per_thread": int(args.variant), "lds_staging": int(args.lds), "pipeline": "split" if args.pipeline == 2 else "fused",
+            "kernel": {"points_per_thread": int(args.variant), "lds_staging": int(args.lds), "pipeline": "fused",
                        "nn_cache": args.nncache, "tile_sorted_scans": int(args.sort), "cell_div": int(args.celldiv)},
         },
         "roofline": {
@@ -581,7 +581,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_source": None if traffic is None else "stored figure: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command run by the "
                               "builder (profiles/r03_traffic.json, profiles/README.md), not a counter of this run",
-            "kernel": "k_s2m_iterate" if args.pipeline != 2 else "k_s2m_cert + k_s2m_scan + k_s2m_fit (one GN iteration)",
+            "kernel": "k_s2m_iterate",
             "ms_per_launch": ms_per_launch,
             "limiter": "not HBM: VALU issue (about 2100 vector instructions per 64 live points and iteration, of which the candidate "
                        "scan is ~40 % and the bit-exact plane fit ~40 %) with the divergent candidate gathers keeping the texture "
@@ -599,9 +599,6 @@ def main():
         "map_build_ms": prof0.map_build_ms, "map_upload_ms": prof0.map_upload_ms,
         "grid_cells": int(prof0.n_cells),
     }
-    if prof is not None and prof.pipeline == 2:
-        out["gn_pipeline"] = {"points_per_iteration": [int(v) for v in prof.cert_points[:n_launch]],
-                              "points_scanned_per_iteration": [int(v) for v in prof.scan_points[:n_launch]]}
 
     if inlib:
         pm = handles[0].profile()

@@ -1,19 +1,19 @@
 // lio_voxsort.h -- K7 (pcl::VoxelGrid centroid filter, MO:1605-1611 / MO:1581-1583) by SORTING: a stable LSD radix sort of
 // (voxel key, input index) pairs through LDS, then one segmented in-order fp32 sum per voxel.
 //
-// Why a second form next to the counting sort of lio_mapbuild.hip: the counting sort keeps three arrays over the whole KEY
-// space (count / start / rank, one int per voxel of the cloud's bounding box, occupied or not).  That is ~1 M keys for a
+// Why a sort (rounds 1-2 used a counting sort): a counting sort keeps three arrays over the whole KEY space (count / start /
+// rank, one int per voxel of the cloud's bounding box, occupied or not).  That is ~1 M keys for a
 // 200-keyframe local map at leaf 0.5 m -- fine -- but a raw 100 m sweep at the reference's smaller scan leaves
 // (mappingSurfLeafSize 0.2 in jeep.yaml:99 / m1.yaml:88, 0.15 in lio_sam_livox.yaml:56) spans 10^8..10^9 voxels of which
 // ~20 k are occupied: gigabytes of memset and scan per callback, and nothing at all above 2^29 voxels although PCL filters
 // up to 2^31.  The sort never looks at the key space: its cost follows the number of POINTS (8 B per point and pass), it
 // handles every key PCL handles, and because an LSD radix sort is stable and the pairs start in input order, every
 // voxel's points arrive in ascending input index -- the order pcl::VoxelGrid's sorted index vector visits them in, which
-// the fp32 running sum depends on -- with no per-voxel sort at all.  Output: ascending voxel key, like the counting sort;
-// the two forms are bit-identical (tests/test_mapbuild.py runs both).
+// the fp32 running sum depends on -- with no per-voxel sort at all.  Output: ascending voxel key.  Measured faster than the counting
+// sort on every input (profiles/r03_k7_forms.txt), which was then removed.
 //
-// One pass = three launches: per-workgroup digit histograms (LDS atomics), an exclusive scan over the [digit][workgroup]
-// table, and the scatter.  A workgroup's tile is laid out wave-striped (item k of lane l of wave w = tile + w*64*ITEMS +
+// One pass = three launches: per-workgroup digit histograms (LDS atomics), an exclusive scan of every digit's row of the
+// [digit][workgroup] table, and the scatter (which adds the prefix over the digits itself).  A workgroup's tile is laid out wave-striped (item k of lane l of wave w = tile + w*64*ITEMS +
 // k*64 + l: coalesced 8-byte loads AND ascending input order along (w, k, l)); the rank of an item among the tile's items
 // of the same digit is found with eight ballots (the lanes holding the same digit), a per-wave LDS counter per digit and
 // a prefix over the four waves -- no atomics, no sort inside the tile, deterministic.
