@@ -97,7 +97,7 @@ def lib_path():
 
 def build_library(verbose=False):
     """hipcc cross-compiles for gfx950 without a GPU (seconds)."""
-    out = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
+    out = subprocess.run(["make", "-j8", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
     if out.returncode != 0:
         raise LioError("building libliogpu.so failed:\n" + out.stdout + out.stderr)
     if verbose:
