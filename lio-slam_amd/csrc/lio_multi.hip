@@ -11,7 +11,8 @@
 //   device c, own stream:   association (k_shard_cull + k_s2m_iterate) -> partial sums d_part[c]
 //                           k_multi_publish: ONE kernel stores d_part[c] into slot c of EVERY device's gather buffer
 //                           (peer-to-peer stores over xGMI; hipDeviceEnablePeerAccess at create time)  -> event pub[c][it]
-//   device p, own stream:   hipStreamWaitEvent on pub[c][it] of every other device c
+//   device p, own stream:   hipStreamWaitEvent on pub[c][it] of every other device c (four devices and more: on ONE event that a
+//                           joining stream records after waiting for all of them -- 2N + 1 host calls instead of N(N-1))
 //                           k_s2m_apply: adds the slots IN DEVICE ORDER (bitwise reproducible, identical on every
 //                           device) and runs LMOptimization MO:1702-1837 for every scan -> identical poses everywhere
 //
@@ -44,6 +45,8 @@ struct LioMulti {
     double* h_tot = nullptr;                          // (host exchange only)
     std::vector<double*> d_tot;                       // (host exchange only)
     std::vector<hipEvent_t> ev_pub;                   // [n_dev][LIO_MAX_ITERS]
+    hipStream_t join_stream = nullptr;                // four devices and more: ONE stream waits for all publish events of an iteration
+    std::vector<hipEvent_t> ev_all;                   // [LIO_MAX_ITERS] ... and records "everybody has published" for every device to wait on
     size_t cap_scans = 0;
     std::vector<std::vector<int>> shard_idx;          // per child: caller's map index of every point of its shard
     std::vector<unsigned char> gather;                // host staging of one shard's records
@@ -147,6 +150,14 @@ int lio_multi_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
                 return lio_fail(LIO_ERR_HIP, "hipEventCreate");
             }
     }
+    if (cfg->n_devices >= 4) {
+        // N devices waiting for N-1 events each is N(N-1) host calls per iteration (56 at N = 8); through one joining stream
+        // it is N + 1 + N (17): the host thread that enqueues everything is the scarce resource of this mode
+        bool ok = hipSetDevice(cfg->device_ids[0]) == hipSuccess && hipStreamCreateWithFlags(&m->join_stream, hipStreamNonBlocking) == hipSuccess;
+        m->ev_all.assign(LIO_MAX_ITERS, nullptr);
+        for (int i = 0; i < LIO_MAX_ITERS && ok; ++i) ok = hipEventCreateWithFlags(&m->ev_all[(size_t)i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { lio_multi_destroy(f); return lio_fail(LIO_ERR_HIP, "hipStreamCreate / hipEventCreate (join stream)"); }
+    }
     *out = f;
     return LIO_OK;
 }
@@ -171,6 +182,9 @@ void lio_multi_destroy(lio_s2m_handle* h)
         lio_s2m_destroy(m->dev[c]);
     }
     if (m->h_tot) (void)hipHostFree(m->h_tot);
+    if (!m->dev.empty()) (void)hipSetDevice(h->cfg.device_ids[0]);
+    for (hipEvent_t e : m->ev_all) if (e) (void)hipEventDestroy(e);
+    if (m->join_stream) (void)hipStreamDestroy(m->join_stream);
     delete m;
     delete h;
 }
@@ -346,10 +360,18 @@ int lio_multi_run(lio_s2m_handle* h)
         }
         if (m->exchange == 2) { const int rc = lio_multi_exchange_host(m, (size_t)n_val); if (rc != LIO_OK) return rc; }
         // join + solve on every device
+        const bool via_join = m->exchange != 2 && m->join_stream != nullptr;
+        if (via_join) {
+            HIPCHK(hipSetDevice(h->cfg.device_ids[0]));
+            for (size_t c = 0; c < nd; ++c) HIPCHK(hipStreamWaitEvent(m->join_stream, m->ev_pub[c * LIO_MAX_ITERS + (size_t)it], 0));
+            HIPCHK(hipEventRecord(m->ev_all[(size_t)it], m->join_stream));
+        }
         for (size_t p = 0; p < nd; ++p) {
             lio_s2m_handle* ch = m->dev[p];
             HIPCHK(hipSetDevice(ch->cfg.device_id));
-            if (m->exchange != 2) {
+            if (via_join) {
+                HIPCHK(hipStreamWaitEvent(ch->stream, m->ev_all[(size_t)it], 0));
+            } else if (m->exchange != 2) {
                 for (size_t c = 0; c < nd; ++c)
                     if (c != p) HIPCHK(hipStreamWaitEvent(ch->stream, m->ev_pub[c * LIO_MAX_ITERS + (size_t)it], 0));
             }

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 TOL_T, TOL_R = 1e-5, 1e-6
 
 
-@pytest.mark.parametrize("n_dev", [2, 3])
+@pytest.mark.parametrize("n_dev", [2, 3, 5])          # (4 and more: the publish events are joined on one stream)
 def test_multi_device_handle_matches_single_device(pkg, oracle, small_case, n_dev):
     one = pkg.ScanToMap(record_corr_iter=0)
     one.set_map(small_case["map"])
@@ -113,16 +113,17 @@ def test_multi_device_lookahead_never_changes_a_result(pkg, small_case):
     qs = small_case["queries"]
     scans = [q["scan"] for q in qs]
     poses0 = np.stack([q["pose_init"] for q in qs])
-    ref = None
-    for look in (0, 1, 4):
-        m = pkg.ScanToMap(n_devices=2, device_ids=[0, 0], lookahead=look)
+    ref = {}
+    for look, nd in ((0, 2), (1, 4), (4, 2), (2, 4)):      # (four devices: the publish events are joined on one stream)
+        m = pkg.ScanToMap(n_devices=nd, device_ids=[0] * nd, lookahead=look)
         m.set_map(small_case["map"])
         for rep in range(2):                               # the second run re-uses the gather buffers and events
             m.batch_upload(scans); m.batch_set_poses(poses0); m.batch_run()
             p, r = m.batch_results()
             got = (p, [x.iters for x in r], [list(x.n_corr_iter) for x in r])
-            if ref is None:
-                ref = got
-            np.testing.assert_array_equal(ref[0], got[0])
-            assert ref[1:] == got[1:]
+            ref.setdefault(nd, got)
+            np.testing.assert_array_equal(ref[nd][0], got[0])         # same device count: the same bits whatever the lookahead
+            assert ref[nd][1:] == got[1:]
         m.close()
+    np.testing.assert_allclose(ref[2][0], ref[4][0], atol=TOL_T)      # another partition of the sums: within tolerance
+    assert ref[2][1:] == ref[4][1:]
