@@ -697,7 +697,10 @@ def main():
     # N > 1, process per GPU: the SAME job-wide batch once more through the in-library mode (ONE process -- rank 0 -- driving all N
     # devices with cfg.n_devices = N, the form a patched node uses), while the other ranks wait on the host (a store key, not a
     # collective: no kernel of theirs spins on a GPU).  Reported beside `value`; a failure here is recorded, never fatal.
-    if runner and world > 1 and extras and os.environ.get("BENCH_BACKEND", "nccl") == "nccl":
+    # OPT-IN (BENCH_INLIB_EXTRA=1): this leg has never run on more than one physical GPU, and a hang inside an extra would
+    # take the whole N > 1 line down with it -- the driver's scaling runs must not depend on it.  `python bench.py --gpus N
+    # --inlib` measures the same thing on its own.
+    if runner and world > 1 and extras and os.environ.get("BENCH_BACKEND", "nccl") == "nccl" and os.environ.get("BENCH_INLIB_EXTRA") == "1":
         from torch.distributed.distributed_c10d import _get_default_store
         kv = _get_default_store()
         sync_all()
