@@ -116,3 +116,21 @@ def test_out_of_range_config_is_refused_not_clamped(pkg, oracle):
     scan = np.zeros((100, 3), np.float32)
     _, res, _, _ = oracle.scan2map(ocfg, scan, scan, np.zeros(6, np.float32))
     assert res.status == -1
+
+
+def test_bench_starts_its_own_ranks_from_the_plain_command():
+    """`python bench.py --gpus 2` with no launcher -- the form the driver records -- must start its ranks itself (a child
+    `python -m torch.distributed.run`), relay their exit code and never touch the GPU in the parent.  Without a GPU the ranks
+    refuse to run ("no CPU fallback"), which is exactly what shows here: the parent spawned them, they said why, rc != 0."""
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box the same command is exercised by the gloo rehearsal (profiles/r03_bench_gloo2_selfspawn_1gpu.json)")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "4", "--no-cpu"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert p.returncode != 0
+    assert "starting 2 ranks" in p.stderr and "torch.distributed.run" in p.stderr
+    assert "bench.py needs a GPU" in p.stderr
+    assert p.stdout.strip() == ""                              # no JSON line without a measurement
