@@ -334,7 +334,7 @@ def main():
     torch.cuda.synchronize()
 
     # -------------------------------------------------------------- engine
-    kcfg = dict(device_id=local_rank, profile=1, use_graph=1 if args.graph else 0, graph_iters=max(args.graph, 1), lookahead=args.lookahead, kernel_variant=args.variant,
+    kcfg = dict(device_id=local_rank, profile=1, max_batch=args.batch, use_graph=1 if args.graph else 0, graph_iters=max(args.graph, 1), lookahead=args.lookahead, kernel_variant=args.variant,
                 use_lds=args.lds, sort_scan=args.sort, cell_div=args.celldiv, xcd_remap=args.xcd, tile_size=args.tile, sort_batch=args.sortbatch, nn_cache=args.nncache,
                 max_sq_dist=args.maxsq, pipeline=args.pipeline)
 

@@ -39,7 +39,7 @@ void lio_launch_aos_to_soa(const void* src, size_t stride, int n, float* x, floa
 void lio_launch_map_bbox(const float* x, const float* y, const float* z, int n, unsigned* bbox, hipStream_t s);
 void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, const float* z, int n,
                           int* cell_of, int* cell_count, int* cell_start, int* tile_sums,
-                          float4* sorted, int* nbr_start, float4* nbr_pts, int* nbr_slot, hipStream_t s);
+                          float4* sorted, int* nbr_start, float4* nbr_pts, int* nbr_slot, bool with_cell_sorted, hipStream_t s);
 int  lio_scan_tiles(int n_cells);
 void lio_launch_init_state(LioScanState* st, int n_scans, float* poses, bool from_state, const LioConsts& c,
                            int* n_active, hipStream_t s);

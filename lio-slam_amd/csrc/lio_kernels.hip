@@ -104,7 +104,7 @@ __global__ void k_map_cell_count(LioGrid g, const float* __restrict__ x, const f
     if (i >= n) return;
     const int c = lio_map_cell(g, x[i], y[i], z[i]);
     cell_of[i] = c;
-    if (c >= 0) atomicAdd(&cell_count[c], 1);
+    if (c >= 0 && cell_count) atomicAdd(&cell_count[c], 1);       // (the counts serve the cell-sorted copy of the LDS-staged variant only)
 }
 
 // exclusive scan of cell_count[0..n) -> cell_start[0..n], three phases
@@ -204,7 +204,10 @@ __global__ void k_map_scatter(const float* __restrict__ x, const float* __restri
 // at its own x cell.  slot[t] = its arrival number in that cell's list (the value the counting atomic returns; -1: no such
 // row), so that k_map_nbr_scatter needs no second round of atomics.  The order inside a list is arbitrary: the candidate
 // scan keeps the five smallest (d2, index) keys whatever order they come in.
-__global__ void k_map_nbr_count(LioGrid g, const int* __restrict__ cell_of, int n, int* __restrict__ nbr_count, int* __restrict__ slot)
+// The bucket of a replica along x is the point's FINE x cell (LioGrid::xs per cell): (4 t) floors into [4 cx, 4 cx + 3] for
+// t = (v - ox) * inv_cell in cell cx (the scaling by a power of two is exact), so a point inside the grid is inside the fine grid.
+__global__ void k_map_nbr_count(LioGrid g, const int* __restrict__ cell_of, const float* __restrict__ x_, int n,
+                                int* __restrict__ nbr_count, int* __restrict__ slot)
 {
     const int side = 2 * g.k + 1, reps = side * side;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,9 +216,10 @@ __global__ void k_map_nbr_count(LioGrid g, const int* __restrict__ cell_of, int 
     const int c = cell_of[i];
     int sl = -1;
     if (c >= 0) {
-        const int x = c % g.nx, yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
+        const int yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
+        const int xf = min(max(lio_cell_coord(x_[i], g.ox, g.inv_cell_x, g.nxf), 0), g.nxf - 1);
         const int yy = y + r % side - g.k, zz = z + r / side - g.k;
-        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) sl = atomicAdd(&nbr_count[(zz * g.ny + yy) * g.nx + x], 1);
+        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) sl = atomicAdd(&nbr_count[(zz * g.ny + yy) * g.nxf + xf], 1);
     }
     slot[t] = sl;
 }
@@ -239,10 +243,10 @@ __global__ __launch_bounds__(256) void k_map_nbr_pad_rows(LioGrid g, int* __rest
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // one wave per row
     if (row >= g.ny * g.nz) return;
     int s = 0;
-    for (int x = lane; x < g.nx; x += 64) s += nbr_count[row * g.nx + x];
+    for (int x = lane; x < g.nxf; x += 64) s += nbr_count[(size_t)row * g.nxf + x];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) nbr_count[row * g.nx + g.nx - 1] += (LIO_ROW_ALIGN - (s & (LIO_ROW_ALIGN - 1))) & (LIO_ROW_ALIGN - 1);
+    if (lane == 0) nbr_count[(size_t)row * g.nxf + g.nxf - 1] += (LIO_ROW_ALIGN - (s & (LIO_ROW_ALIGN - 1))) & (LIO_ROW_ALIGN - 1);
 }
 
 __global__ void k_map_nbr_fill(float4* __restrict__ nbr_pts, int n_rec4)
@@ -267,9 +271,10 @@ __global__ void k_map_nbr_scatter(LioGrid g, const float* __restrict__ x_, const
     if (sl < 0) return;
     const int i = (int)(t / reps), r = (int)(t - (long long)i * reps);
     const int c = cell_of[i];
-    const int x = c % g.nx, yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
+    const int yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
+    const int xf = min(max(lio_cell_coord(x_[i], g.ox, g.inv_cell_x, g.nxf), 0), g.nxf - 1);
     const int yy = y + r % side - g.k, zz = z + r / side - g.k;
-    lio_nbr_store(reinterpret_cast<float*>(nbr_pts), nbr_start[(zz * g.ny + yy) * g.nx + x] + sl, x_[i], y_[i], z_[i], __int_as_float(i));
+    lio_nbr_store(reinterpret_cast<float*>(nbr_pts), nbr_start[(zz * g.ny + yy) * g.nxf + xf] + sl, x_[i], y_[i], z_[i], __int_as_float(i));
 }
 
 // ------------------------------------------------- scan tile sort (upload)
@@ -961,7 +966,7 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
         // the sentinel.  R is rounded up by 1e-4 (fp32 rounding of the distances is 1e-7).  Typically
         // R ~ 0.5 m against the 1 m gate: half the candidate run.  One float per point is kept.
         float bound2 = P.c.max_sq_dist;
-        int xlo = -0x7fffffff, xhi = 0x7fffffff;
+        float Rx = sqrtf(P.c.max_sq_dist) * 1.0001f + 1e-6f;          // reach along x: the gate, unless the bound below is tighter
         const int ci = base + bd.first + pp * LIO_BLOCK + (int)threadIdx.x;   // slot in the batch SoA
         if (use_cache && act[pp]) {
             const float d5 = P.d5_cache[ci];
@@ -972,11 +977,7 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
                 const float mv = sqrtf(lio_sqdist(qx[pp], qy[pp], qz[pp], ox, oy, oz));
                 const float R = (sqrtf(d5) + mv) * 1.0001f + 1e-6f;
                 const float r2 = R * R * 1.0001f;
-                if (r2 < bound2) {
-                    bound2 = r2;
-                    xlo = lio_cell_coord(qx[pp] - R, g.ox, g.inv_cell, g.nx);
-                    xhi = lio_cell_coord(qx[pp] + R, g.ox, g.inv_cell, g.nx);
-                }
+                if (r2 < bound2) { bound2 = r2; Rx = R; }
             }
         }
         // (d2 == bound2 with any real index sorts below the sentinel, so ties at the bound are kept)
@@ -987,7 +988,8 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
                 lio_knn_lds(s_pts, s_cell, rxn1, ryn, rx0, ry0, rz0, ry1, rz1, g.nx, g.k,
                             qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], top);
             else
-                lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], xlo, xhi, top);
+                lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cy[pp], cz[pp], lio_cell_coord(qx[pp] - Rx, g.ox, g.inv_cell_x, g.nxf),
+                               lio_cell_coord(qx[pp] + Rx, g.ox, g.inv_cell_x, g.nxf), top);
         }
         // gate MO:1641: pointSearchSqDis[4] < 1.0
         const bool ok = act[pp] && (lio_key_d2(top.k4) < P.c.max_sq_dist);
@@ -1112,22 +1114,33 @@ void lio_launch_exclusive_scan(const int* in, int n, int* tile_sums, int* out, h
 // nbr_slot: n x (2k+1)^2 ints
 void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, const float* z, int n,
                           int* cell_of, int* cell_count, int* cell_start, int* tile_sums,
-                          float4* sorted, int* nbr_start, float4* nbr_pts, int* nbr_slot, hipStream_t s)
+                          float4* sorted, int* nbr_start, float4* nbr_pts, int* nbr_slot, bool with_cell_sorted, hipStream_t s)
 {
     const int nb = (n + 255) / 256;
     const long long n_rep = (long long)n * (2 * g.k + 1) * (2 * g.k + 1);
     const unsigned nbr = (unsigned)((n_rep + 255) / 256);
     int* nbr_count = cell_count + g.n_cells;
     unsigned long long* tiles64 = reinterpret_cast<unsigned long long*>(tile_sums);
-    (void)hipMemsetAsync(cell_count, 0, sizeof(int) * 2 * (size_t)g.n_cells, s);
-    hipLaunchKernelGGL(k_map_cell_count, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, cell_count);
-    hipLaunchKernelGGL(k_map_nbr_count, dim3(nbr), dim3(256), 0, s, g, cell_of, n, nbr_count, nbr_slot);
+    // with_cell_sorted: also the cell-sorted 1x copy + cell_start the LDS-staged variant (cfg.use_lds) walks; the default
+    // candidate scan only needs the replicated rows, and a node rebuilds this for every scan: nothing it does not read
+    if (with_cell_sorted) (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells * (1 + g.xs), s);
+    else (void)hipMemsetAsync(nbr_count, 0, sizeof(int) * (size_t)g.n_cells * g.xs, s);
+    hipLaunchKernelGGL(k_map_cell_count, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, with_cell_sorted ? cell_count : (int*)nullptr);
+    hipLaunchKernelGGL(k_map_nbr_count, dim3(nbr), dim3(256), 0, s, g, cell_of, x, n, nbr_count, nbr_slot);
     hipLaunchKernelGGL(k_map_nbr_pad_rows, dim3((g.ny * g.nz + 3) / 4), dim3(256), 0, s, g, nbr_count);
-    // cell_start (cell-sorted copy, 1x: the LDS-staged variant) and nbr_start (replicated neighbourhood rows: the default
-    // candidate scan) in one scan pass
-    lio_launch_scan2<false>(cell_count, nbr_count, g.n_cells, tiles64, cell_start, nbr_start, s);
-    (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);       // reused as the fill cursor of the cell-sorted copy
-    hipLaunchKernelGGL(k_map_scatter, dim3(nb), dim3(256), 0, s, x, y, z, n, cell_of, cell_start, cell_count, sorted);
+    if (!with_cell_sorted) {
+        lio_launch_exclusive_scan(nbr_count, g.n_cells * g.xs, tile_sums, nbr_start, s);
+    } else {
+        // one pass carrying both sums while the two tables have the same length (xs = 1), two passes otherwise
+        if (g.xs == 1) {
+            lio_launch_scan2<false>(cell_count, nbr_count, g.n_cells, tiles64, cell_start, nbr_start, s);
+        } else {
+            lio_launch_exclusive_scan(cell_count, g.n_cells, tile_sums, cell_start, s);
+            lio_launch_exclusive_scan(nbr_count, g.n_cells * g.xs, tile_sums, nbr_start, s);
+        }
+        (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);       // reused as the fill cursor of the cell-sorted copy
+        hipLaunchKernelGGL(k_map_scatter, dim3(nb), dim3(256), 0, s, x, y, z, n, cell_of, cell_start, cell_count, sorted);
+    }
     {
         const int n_rec4 = n * (2 * g.k + 1) * (2 * g.k + 1) + LIO_ROW_ALIGN * g.ny * g.nz + 2 * LIO_ROW_ALIGN;   // + row and tail padding
         hipLaunchKernelGGL(k_map_nbr_fill, dim3((n_rec4 + 255) / 256), dim3(256), 0, s, nbr_pts, n_rec4);

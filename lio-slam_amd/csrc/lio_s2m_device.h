@@ -253,13 +253,13 @@ LIO_DEV void lio_knn_group(const float4& c0, const float4& c1, const float4& c2,
 }
 
 LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
-                            int cx, int cy, int cz, int xlo, int xhi, LioTop5& top)
+                            int cy, int cz, int xlo, int xhi, LioTop5& top)
 {
-    // [xlo, xhi]: x-cells that can hold a point closer than the current bound (the whole +-k range
-    // unless the previous iteration's neighbours gave a tighter one, see "neighbour cache" below)
-    const int x0 = max(max(cx - g.k, 0), xlo), x1 = min(min(cx + g.k, g.nx - 1), xhi);
+    // [xlo, xhi]: FINE x cells (LioGrid::xs per cell) that can hold a point closer than the current bound: the gate radius,
+    // or the tighter bound the previous iteration's neighbours gave (see "neighbour cache" in the kernels)
+    const int x0 = max(xlo, 0), x1 = min(xhi, g.nxf - 1);
     if (x0 > x1) return;
-    const int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nx;
+    const int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nxf;
 #if LIO_PREFETCH == 3
     const unsigned beg = (unsigned)P.nbr_start[row + x0] & ~7u;
 #else

@@ -18,6 +18,12 @@ struct LioGrid {
     int32_t nx, ny, nz;
     int32_t n_cells;
     int32_t k;          // neighbourhood radius in cells (cell edge = search radius / k)
+    // The replicated neighbourhood rows are bucketed along x `xs` times finer than the cells (rows stay one cell high and
+    // deep): a query's run [x-cell(qx - R), x-cell(qx + R)] is cut to a quarter of a cell instead of a whole one -- fewer
+    // candidates for the same exact search (round 3; xs = 1 is the round-2 layout).
+    int32_t xs;         // x subdivision of the row buckets (1, 2, 4, 8)
+    int32_t nxf;        // nx * xs
+    float inv_cell_x;   // inv_cell * xs (exact: xs is a power of two)
 };
 
 // Owner-computes predicate for a map sharded across GPUs: a scan

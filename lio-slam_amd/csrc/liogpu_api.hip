@@ -66,6 +66,7 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->pipeline = 0;
     c->n_devices = 1;
     for (int i = 0; i < 8; ++i) c->device_ids[i] = i;
+    c->x_sub = 0;
 }
 
 static void lio_fill_consts(lio_s2m_handle* h)
@@ -107,6 +108,8 @@ extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
     if (cfg->k != 5) return lio_fail(LIO_ERR_ARG, "only k = 5 is supported (MO:1631)");
     if (cfg->max_iters < 1 || cfg->max_iters > LIO_MAX_ITERS) return lio_fail(LIO_ERR_ARG, "max_iters out of range");
     if (!(cfg->max_sq_dist > 0.0f)) return lio_fail(LIO_ERR_ARG, "max_sq_dist must be positive");
+    if (cfg->x_sub != 0 && cfg->x_sub != 1 && cfg->x_sub != 2 && cfg->x_sub != 4 && cfg->x_sub != 8)
+        return lio_fail(LIO_ERR_ARG, "cfg.x_sub must be 0 (auto), 1, 2, 4 or 8");
     if (cfg->pipeline != 0 && cfg->pipeline != 1 && cfg->pipeline != 4)
         return lio_fail(LIO_ERR_ARG, "cfg.pipeline must be 0 (auto), 1 (one launch per iteration) or 4 (one-launch loop)");
     int ndev = 0;
@@ -229,6 +232,10 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
     int kdiv = h->cfg.cell_div;
     if (kdiv != 1 && kdiv != 2 && kdiv != 3) kdiv = 2;
     float cell = (h->cfg.cell_size > 0.0f ? h->cfg.cell_size : sqrtf(h->cfg.max_sq_dist) * 1.001f) / (float)kdiv;
+    // x subdivision of the row buckets (LioGrid::xs, cfg.x_sub): auto = 4 for a batch handle, 1 for a node's handle (measured,
+    // DESIGN.md section 6); LIO_X_SUB = 1 | 2 | 4 | 8 in the environment overrides it for A/B runs
+    int xsub = h->cfg.x_sub > 0 ? h->cfg.x_sub : (h->cfg.max_batch >= 8 ? 4 : 1);
+    { const char* e = getenv("LIO_X_SUB"); const int v = e ? atoi(e) : 0; if (v == 1 || v == 2 || v == 4 || v == 8) xsub = v; }
     LioGrid g;
     for (;;) {
         g.k = kdiv;
@@ -237,28 +244,29 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
         const double ex = ((double)mx[0] - g.ox) * g.inv_cell, ey = ((double)mx[1] - g.oy) * g.inv_cell,
                      ez = ((double)mx[2] - g.oz) * g.inv_cell;
         const double cells = (floor(ex) + 2.0) * (floor(ey) + 2.0) * (floor(ez) + 2.0);
-        if (cells <= 256.0 * 1024.0 * 1024.0) {
+        if (cells * xsub <= 256.0 * 1024.0 * 1024.0) {
             g.nx = (int)floor(ex) + 2; g.ny = (int)floor(ey) + 2; g.nz = (int)floor(ez) + 2;
             g.n_cells = g.nx * g.ny * g.nz;
             break;
         }
         cell *= 1.5f;   // larger cells keep the search exact, only less selective
     }
+    g.xs = xsub; g.nxf = g.nx * xsub; g.inv_cell_x = g.inv_cell * (float)xsub;
     h->grid = g;
-    HIPCHK(lio_grow(&h->d_cell_count, &h->cap_cell_count, 2 * (size_t)g.n_cells));       // (point counts + neighbourhood-row lengths)
+    HIPCHK(lio_grow(&h->d_cell_count, &h->cap_cell_count, (size_t)g.n_cells * (1 + xsub)));   // (point counts + neighbourhood-row bucket lengths)
     HIPCHK(lio_grow(&h->d_cell_start, &h->cap_cell_start, (size_t)g.n_cells + 1));
-    HIPCHK(lio_grow(&h->d_nbr_start, &h->cap_nbr_start, (size_t)g.n_cells + 1));
+    HIPCHK(lio_grow(&h->d_nbr_start, &h->cap_nbr_start, (size_t)g.n_cells * xsub + 1));
     HIPCHK(lio_grow(&h->d_nbr_pts, &h->cap_nbr_pts, nn * (size_t)((2 * g.k + 1) * (2 * g.k + 1)) + LIO_ROW_ALIGN * (size_t)g.ny * g.nz + 4 * LIO_ROW_ALIGN, 1.05));
-    HIPCHK(lio_grow(&h->d_tile_sums, &h->cap_tile_sums, 2 * ((size_t)lio_scan_tiles(g.n_cells) + 1)));   // (64-bit pair sums)
+    HIPCHK(lio_grow(&h->d_tile_sums, &h->cap_tile_sums, 2 * ((size_t)lio_scan_tiles(g.n_cells * xsub) + 1)));   // (64-bit pair sums)
     HIPCHK(lio_grow(&h->d_nbr_slot, &h->cap_nbr_slot, nn * (size_t)((2 * g.k + 1) * (2 * g.k + 1)), 1.05));
 
     HIPCHK(hipEventRecord(box ? h->ev_mapl[0] : h->ev_map[0], h->stream));
     if (n) {
         lio_launch_map_build(g, h->d_mx, h->d_my, h->d_mz, (int)n, h->d_cell_of, h->d_cell_count,
-                             h->d_cell_start, h->d_tile_sums, h->d_sorted, h->d_nbr_start, h->d_nbr_pts, h->d_nbr_slot, h->stream);
+                             h->d_cell_start, h->d_tile_sums, h->d_sorted, h->d_nbr_start, h->d_nbr_pts, h->d_nbr_slot, h->cfg.use_lds != 0, h->stream);
     } else {
         HIPCHK(hipMemsetAsync(h->d_cell_start, 0, sizeof(int) * ((size_t)g.n_cells + 1), h->stream));
-        HIPCHK(hipMemsetAsync(h->d_nbr_start, 0, sizeof(int) * ((size_t)g.n_cells + 1), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_nbr_start, 0, sizeof(int) * ((size_t)g.n_cells * xsub + 1), h->stream));
     }
     HIPCHK(hipEventRecord(box ? h->ev_mapl[1] : h->ev_map[1], h->stream));
     HIPCHK(hipGetLastError());
@@ -368,6 +376,8 @@ extern "C" int lio_s2m_share_map(lio_s2m_handle* h, lio_s2m_handle* map_owner)
     if (h->multi || (map_owner && map_owner->multi)) return lio_fail(LIO_ERR_ARG, "not available on a multi-device handle");
     if (map_owner && (map_owner->map_src || map_owner->cfg.device_id != h->cfg.device_id))
         return lio_fail(LIO_ERR_ARG, "the map owner must hold its own map on the same device");
+    if (map_owner && h->cfg.use_lds && !map_owner->cfg.use_lds)
+        return lio_fail(LIO_ERR_ARG, "cfg.use_lds needs the cell-sorted copy of the map, which only an owner created with use_lds builds");
     h->map_src = map_owner;
     h->map_epoch = map_owner ? map_owner->map_epoch : 0;
     h->graph_dirty = true;

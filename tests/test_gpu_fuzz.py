@@ -49,7 +49,7 @@ def test_random_plane_soup(pkg, oracle, seed):
     scan = (_planes(rng, 25, 300, 25.0, 0.05) ).astype(np.float32)
     scan = np.concatenate([scan, map_xyz[rng.choice(len(map_xyz), 2000)] + rng.normal(0, 0.05, (2000, 3)).astype(np.float32)])
     pose = np.concatenate([rng.normal(0, 0.02, 3), rng.normal(0, 0.1, 3)]).astype(np.float32)
-    n_acc, n_gate = _check(pkg, oracle, scan, map_xyz, pose, cell_div=1 + seed % 3)
+    n_acc, n_gate = _check(pkg, oracle, scan, map_xyz, pose, cell_div=1 + seed % 3, x_sub=(1, 4, 2, 8, 4, 1)[seed])
     assert n_gate > 500
 
 
@@ -72,6 +72,7 @@ def test_collinear_and_duplicate_neighbours(pkg, oracle):
     scan = np.concatenate([line[::3] + np.array([0.05, 0.02, 0.01], np.float32), dup[::6] + 0.01,
                            rng.normal(0, 0.1, (50, 3)).astype(np.float32), _planes(rng, 4, 100, 5.0, 0.03).astype(np.float32)])
     _check(pkg, oracle, scan.astype(np.float32), map_xyz, np.zeros(6, np.float32))
+    _check(pkg, oracle, scan.astype(np.float32), map_xyz, np.zeros(6, np.float32), x_sub=4)
 
 
 @pytest.mark.parametrize("offset", [(5000.0, -3000.0, 120.0), (-65536.0, 131072.0, 0.0)])
@@ -85,6 +86,9 @@ def test_large_coordinates(pkg, oracle, offset):
     pose = np.array([0.01, -0.02, 0.03, off[0] + 0.05, off[1] - 0.04, off[2] + 0.02], np.float32)
     n_acc, n_gate = _check(pkg, oracle, scan, map_xyz, pose)
     assert n_gate > 300
+    # finer x buckets: at 131072 m one fp32 step is 1.6 cm, a fine cell (0.25 m / 4) holds four of them
+    assert _check(pkg, oracle, scan, map_xyz, pose, x_sub=8, cell_div=3) == (n_acc, n_gate)
+    assert _check(pkg, oracle, scan, map_xyz, pose, x_sub=4) == (n_acc, n_gate)
 
 
 def test_scan_partly_outside_the_map_and_nonfinite_points(pkg, oracle):
@@ -93,6 +97,7 @@ def test_scan_partly_outside_the_map_and_nonfinite_points(pkg, oracle):
     scan = np.concatenate([_planes(rng, 8, 200, 6.0, 0.04), rng.uniform(-500, 500, (500, 3)),
                            rng.uniform(1e6, 1e7, (20, 3))]).astype(np.float32)
     _check(pkg, oracle, scan, map_xyz, np.zeros(6, np.float32))
+    _check(pkg, oracle, scan, map_xyz, np.zeros(6, np.float32), x_sub=4)
     # non-finite map points are ignored by both sides (they can never be within 1 m of anything)
     bad = map_xyz.copy()
     bad[::50] = np.nan
