@@ -110,6 +110,11 @@ typedef struct lio_s2m_config {
                                 bucket table, +0.08 ms per map build.  0 = auto: 4 for a handle set up for batches
                                 (max_batch >= 8: the map is built once and searched by many scans), 1 for a node's handle
                                 (the map is rebuilt for every scan; a lone registration is latency-bound and gains nothing) */
+    int32_t tight_rows;      /* a second set of neighbourhood rows over the same points with 3x3 cells of 0.6 x the gate
+                                radius (+36 % map memory, +0.1 ms per map build): a query whose search bound -- the previous
+                                iteration's fifth neighbour plus its own movement -- is at most that walks a (1.8 m)^2
+                                cross-section instead of (2.5 m)^2; same results, -3 % per launch on the 512-scan batches.
+                                0 = auto (as x_sub: on for max_batch >= 8), 1 = on, -1 = off                              */
 } lio_s2m_config;
 
 /* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in

@@ -33,7 +33,7 @@ class S2MConfig(C.Structure):
         ("profile", C.c_int32), ("lookahead", C.c_int32), ("use_lds", C.c_int32), ("sort_scan", C.c_int32),
         ("cell_div", C.c_int32), ("xcd_remap", C.c_int32), ("tile_size", C.c_float),
         ("use_graph", C.c_int32), ("graph_iters", C.c_int32), ("sort_batch", C.c_int32), ("nn_cache", C.c_int32),
-        ("pipeline", C.c_int32), ("n_devices", C.c_int32), ("device_ids", C.c_int32 * 8), ("x_sub", C.c_int32),
+        ("pipeline", C.c_int32), ("n_devices", C.c_int32), ("device_ids", C.c_int32 * 8), ("x_sub", C.c_int32), ("tight_rows", C.c_int32),
     ]
 
 

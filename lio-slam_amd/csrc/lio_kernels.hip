@@ -206,17 +206,18 @@ __global__ void k_map_scatter(const float* __restrict__ x, const float* __restri
 // scan keeps the five smallest (d2, index) keys whatever order they come in.
 // The bucket of a replica along x is the point's FINE x cell (LioGrid::xs per cell): (4 t) floors into [4 cx, 4 cx + 3] for
 // t = (v - ox) * inv_cell in cell cx (the scaling by a power of two is exact), so a point inside the grid is inside the fine grid.
-__global__ void k_map_nbr_count(LioGrid g, const int* __restrict__ cell_of, const float* __restrict__ x_, int n,
-                                int* __restrict__ nbr_count, int* __restrict__ slot)
+// (g.oy/oz/inv_cell/ny/nz/k describe the table being built: the grid's own rows, or its tight rows -- lio_tight_grid.)
+__global__ void k_map_nbr_count(LioGrid g, const int* __restrict__ cell_of, const float* __restrict__ x_, const float* __restrict__ y_,
+                                const float* __restrict__ z_, int n, int* __restrict__ nbr_count, int* __restrict__ slot)
 {
     const int side = 2 * g.k + 1, reps = side * side;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)n * reps) return;
     const int i = (int)(t / reps), r = (int)(t - (long long)i * reps);
-    const int c = cell_of[i];
     int sl = -1;
-    if (c >= 0) {
-        const int yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
+    if (cell_of[i] >= 0) {                                              // (a finite point inside the grid)
+        const int y = min(max(lio_cell_coord(y_[i], g.oy, g.inv_cell, g.ny), 0), g.ny - 1);
+        const int z = min(max(lio_cell_coord(z_[i], g.oz, g.inv_cell, g.nz), 0), g.nz - 1);
         const int xf = min(max(lio_cell_coord(x_[i], g.ox, g.inv_cell_x, g.nxf), 0), g.nxf - 1);
         const int yy = y + r % side - g.k, zz = z + r / side - g.k;
         if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) sl = atomicAdd(&nbr_count[(zz * g.ny + yy) * g.nxf + xf], 1);
@@ -260,7 +261,7 @@ __global__ void k_map_nbr_fill(float4* __restrict__ nbr_pts, int n_rec4)
 }
 
 __global__ void k_map_nbr_scatter(LioGrid g, const float* __restrict__ x_, const float* __restrict__ y_,
-                                  const float* __restrict__ z_, int n, const int* __restrict__ cell_of,
+                                  const float* __restrict__ z_, int n,
                                   const int* __restrict__ nbr_start, const int* __restrict__ slot,
                                   float4* __restrict__ nbr_pts)
 {
@@ -270,8 +271,8 @@ __global__ void k_map_nbr_scatter(LioGrid g, const float* __restrict__ x_, const
     const int sl = slot[t];
     if (sl < 0) return;
     const int i = (int)(t / reps), r = (int)(t - (long long)i * reps);
-    const int c = cell_of[i];
-    const int yz = c / g.nx, y = yz % g.ny, z = yz / g.ny;
+    const int y = min(max(lio_cell_coord(y_[i], g.oy, g.inv_cell, g.ny), 0), g.ny - 1);
+    const int z = min(max(lio_cell_coord(z_[i], g.oz, g.inv_cell, g.nz), 0), g.nz - 1);
     const int xf = min(max(lio_cell_coord(x_[i], g.ox, g.inv_cell_x, g.nxf), 0), g.nxf - 1);
     const int yy = y + r % side - g.k, zz = z + r / side - g.k;
     lio_nbr_store(reinterpret_cast<float*>(nbr_pts), nbr_start[(zz * g.ny + yy) * g.nxf + xf] + sl, x_[i], y_[i], z_[i], __int_as_float(i));
@@ -988,17 +989,16 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
                 lio_knn_lds(s_pts, s_cell, rxn1, ryn, rx0, ry0, rz0, ry1, rz1, g.nx, g.k,
                             qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], top);
             else
-                lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cy[pp], cz[pp], lio_cell_coord(qx[pp] - Rx, g.ox, g.inv_cell_x, g.nxf),
-                               lio_cell_coord(qx[pp] + Rx, g.ox, g.inv_cell_x, g.nxf), top);
+                lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cy[pp], cz[pp], Rx, top);
         }
+        int nn[5] = { lio_key_idx(top.k0), lio_key_idx(top.k1), lio_key_idx(top.k2), lio_key_idx(top.k3), lio_key_idx(top.k4) };
+        const float d2_5 = lio_key_d2(top.k4);
         // gate MO:1641: pointSearchSqDis[4] < 1.0
-        const bool ok = act[pp] && (lio_key_d2(top.k4) < P.c.max_sq_dist);
+        const bool ok = act[pp] && (d2_5 < P.c.max_sq_dist);
         if (pp == 0) LIO_STAMP(2);
 
-        int nn[5] = { lio_key_idx(top.k0), lio_key_idx(top.k1), lio_key_idx(top.k2),
-                      lio_key_idx(top.k3), lio_key_idx(top.k4) };
         if (P.d5_cache && inr[pp])                                    // for the next iteration (-1: nothing to re-use)
-            P.d5_cache[ci] = ok ? lio_key_d2(top.k4) : -1.0f;
+            P.d5_cache[ci] = ok ? d2_5 : -1.0f;
         float cxx = 0.0f, cyy = 0.0f, czz = 0.0f, cww = 0.0f;
         bool accept = false;
         // plane through the five neighbours, plane test, weight, coefficients MO:1642-1683 (the CORNER extension: point-to-line);
@@ -1112,40 +1112,55 @@ void lio_launch_exclusive_scan(const int* in, int n, int* tile_sums, int* out, h
 // cell_count: 2 x n_cells ints (point counts, then neighbourhood-row lengths; both reused as fill cursors);
 // tile_sums: 2 x (lio_scan_tiles(n_cells) + 1) ints, 8-byte aligned (one 64-bit pair sum per tile)
 // nbr_slot: n x (2k+1)^2 ints
+static LioGrid lio_tight_grid(const LioGrid& g)
+{
+    LioGrid b = g;                      // same x buckets; its own (y, z) cells, k = 1
+    b.oy = g.tb_oy; b.oz = g.tb_oz; b.inv_cell = g.tb_inv_cell; b.ny = g.tb_ny; b.nz = g.tb_nz; b.k = 1;
+    return b;
+}
+
 void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, const float* z, int n,
                           int* cell_of, int* cell_count, int* cell_start, int* tile_sums,
                           float4* sorted, int* nbr_start, float4* nbr_pts, int* nbr_slot, bool with_cell_sorted, hipStream_t s)
 {
     const int nb = (n + 255) / 256;
-    const long long n_rep = (long long)n * (2 * g.k + 1) * (2 * g.k + 1);
-    const unsigned nbr = (unsigned)((n_rep + 255) / 256);
+    const int repsA = (2 * g.k + 1) * (2 * g.k + 1), repsB = 9;
+    const bool tight = g.tb_reach > 0.0f;
+    const LioGrid gb = lio_tight_grid(g);
+    const int lenA = g.n_cells * g.xs, lenB = tight ? g.tb_ny * g.tb_nz * g.nxf : 0;      // buckets of the two row tables
+    const unsigned nbrA = (unsigned)(((long long)n * repsA + 255) / 256), nbrB = (unsigned)(((long long)n * repsB + 255) / 256);
     int* nbr_count = cell_count + g.n_cells;
+    int* slotB = nbr_slot + (size_t)n * repsA;
     unsigned long long* tiles64 = reinterpret_cast<unsigned long long*>(tile_sums);
     // with_cell_sorted: also the cell-sorted 1x copy + cell_start the LDS-staged variant (cfg.use_lds) walks; the default
     // candidate scan only needs the replicated rows, and a node rebuilds this for every scan: nothing it does not read
-    if (with_cell_sorted) (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells * (1 + g.xs), s);
-    else (void)hipMemsetAsync(nbr_count, 0, sizeof(int) * (size_t)g.n_cells * g.xs, s);
+    if (with_cell_sorted) (void)hipMemsetAsync(cell_count, 0, sizeof(int) * ((size_t)g.n_cells + lenA + lenB), s);
+    else (void)hipMemsetAsync(nbr_count, 0, sizeof(int) * ((size_t)lenA + lenB), s);
     hipLaunchKernelGGL(k_map_cell_count, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, with_cell_sorted ? cell_count : (int*)nullptr);
-    hipLaunchKernelGGL(k_map_nbr_count, dim3(nbr), dim3(256), 0, s, g, cell_of, x, n, nbr_count, nbr_slot);
+    hipLaunchKernelGGL(k_map_nbr_count, dim3(nbrA), dim3(256), 0, s, g, cell_of, x, y, z, n, nbr_count, nbr_slot);
     hipLaunchKernelGGL(k_map_nbr_pad_rows, dim3((g.ny * g.nz + 3) / 4), dim3(256), 0, s, g, nbr_count);
-    if (!with_cell_sorted) {
-        lio_launch_exclusive_scan(nbr_count, g.n_cells * g.xs, tile_sums, nbr_start, s);
+    if (tight) {
+        hipLaunchKernelGGL(k_map_nbr_count, dim3(nbrB), dim3(256), 0, s, gb, cell_of, x, y, z, n, nbr_count + lenA, slotB);
+        hipLaunchKernelGGL(k_map_nbr_pad_rows, dim3((gb.ny * gb.nz + 3) / 4), dim3(256), 0, s, gb, nbr_count + lenA);
+    }
+    // one exclusive scan over the buckets of both tables: the tight rows' records follow the grid's own in nbr_pts
+    if (with_cell_sorted && g.xs == 1 && !tight) {
+        // (one pass carrying both sums while the two tables have the same length)
+        lio_launch_scan2<false>(cell_count, nbr_count, g.n_cells, tiles64, cell_start, nbr_start, s);
     } else {
-        // one pass carrying both sums while the two tables have the same length (xs = 1), two passes otherwise
-        if (g.xs == 1) {
-            lio_launch_scan2<false>(cell_count, nbr_count, g.n_cells, tiles64, cell_start, nbr_start, s);
-        } else {
-            lio_launch_exclusive_scan(cell_count, g.n_cells, tile_sums, cell_start, s);
-            lio_launch_exclusive_scan(nbr_count, g.n_cells * g.xs, tile_sums, nbr_start, s);
-        }
+        if (with_cell_sorted) lio_launch_exclusive_scan(cell_count, g.n_cells, tile_sums, cell_start, s);
+        lio_launch_exclusive_scan(nbr_count, lenA + lenB, tile_sums, nbr_start, s);
+    }
+    if (with_cell_sorted) {
         (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);       // reused as the fill cursor of the cell-sorted copy
         hipLaunchKernelGGL(k_map_scatter, dim3(nb), dim3(256), 0, s, x, y, z, n, cell_of, cell_start, cell_count, sorted);
     }
     {
-        const int n_rec4 = n * (2 * g.k + 1) * (2 * g.k + 1) + LIO_ROW_ALIGN * g.ny * g.nz + 2 * LIO_ROW_ALIGN;   // + row and tail padding
+        const int n_rec4 = n * (repsA + (tight ? repsB : 0)) + LIO_ROW_ALIGN * (g.ny * g.nz + (tight ? gb.ny * gb.nz : 0)) + 2 * LIO_ROW_ALIGN;   // + row and tail padding
         hipLaunchKernelGGL(k_map_nbr_fill, dim3((n_rec4 + 255) / 256), dim3(256), 0, s, nbr_pts, n_rec4);
     }
-    hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nbr), dim3(256), 0, s, g, x, y, z, n, cell_of, nbr_start, nbr_slot, nbr_pts);
+    hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nbrA), dim3(256), 0, s, g, x, y, z, n, nbr_start, nbr_slot, nbr_pts);
+    if (tight) hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nbrB), dim3(256), 0, s, gb, x, y, z, n, nbr_start + lenA, slotB, nbr_pts);
 }
 
 int lio_scan_tiles(int n_cells) { return (n_cells + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE; }

@@ -168,8 +168,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
         }
         const double sentinel = lio_make_key(bound2, -1);
         LioTop5 top = { sentinel, sentinel, sentinel, sentinel, sentinel };
-        if (act) lio_knn_global(P, g, qx, qy, qz, cy, cz, lio_cell_coord(qx - Rx, g.ox, g.inv_cell_x, g.nxf),
-                                lio_cell_coord(qx + Rx, g.ox, g.inv_cell_x, g.nxf), top);
+        if (act) lio_knn_global(P, g, qx, qy, qz, cy, cz, Rx, top);
         const bool ok = act && (lio_key_d2(top.k4) < P.c.max_sq_dist);       // gate MO:1641
         const int nn[5] = { lio_key_idx(top.k0), lio_key_idx(top.k1), lio_key_idx(top.k2), lio_key_idx(top.k3), lio_key_idx(top.k4) };
         if (P.d5_cache && inr) P.d5_cache[ci] = ok ? lio_key_d2(top.k4) : -1.0f;

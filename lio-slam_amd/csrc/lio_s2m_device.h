@@ -252,20 +252,35 @@ LIO_DEV void lio_knn_group(const float4& c0, const float4& c1, const float4& c2,
     lio_top5_insert4(top, k0, k1, k2, k3);
 }
 
-LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
-                            int cy, int cz, int xlo, int xhi, LioTop5& top)
+// The candidate run of one query: [beg, end) records of nbr_pts (beg aligned down to a whole group), empty: beg >= end.
+LIO_DEV void lio_knn_range(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
+                           int cy, int cz, float Rx, unsigned& beg, unsigned& end)
 {
-    // [xlo, xhi]: FINE x cells (LioGrid::xs per cell) that can hold a point closer than the current bound: the gate radius,
-    // or the tighter bound the previous iteration's neighbours gave (see "neighbour cache" in the kernels)
+    // Rx: the current search bound -- the gate radius, or the tighter bound the previous iteration's neighbours gave (see
+    // "neighbour cache" in the kernels); [xlo, xhi]: the FINE x cells (LioGrid::xs per cell) that can hold a point within it
+    const int xlo = lio_cell_coord(qx - Rx, g.ox, g.inv_cell_x, g.nxf), xhi = lio_cell_coord(qx + Rx, g.ox, g.inv_cell_x, g.nxf);
     const int x0 = max(xlo, 0), x1 = min(xhi, g.nxf - 1);
+    beg = end = 0;
     if (x0 > x1) return;
-    const int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nxf;
+    int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nxf;
+    if (Rx <= g.tb_reach) {
+        // tight rows (LioGrid::tb_*): every map point within Rx of the query lies in the 3x3 cells around the query's cell
+        // of the coarser-celled second table, i.e. in that cell's row; a query outside the grid is clamped as above
+        const int by = min(max(lio_cell_coord(qy, g.tb_oy, g.tb_inv_cell, g.tb_ny), 0), g.tb_ny - 1);
+        const int bz = min(max(lio_cell_coord(qz, g.tb_oz, g.tb_inv_cell, g.tb_nz), 0), g.tb_nz - 1);
+        row = g.tb_row0 + (bz * g.tb_ny + by) * g.nxf;
+    }
 #if LIO_PREFETCH == 3
-    const unsigned beg = (unsigned)P.nbr_start[row + x0] & ~7u;
+    beg = (unsigned)P.nbr_start[row + x0] & ~7u;
 #else
-    const unsigned beg = (unsigned)P.nbr_start[row + x0] & ~3u;
+    beg = (unsigned)P.nbr_start[row + x0] & ~3u;
 #endif
-    const unsigned end = (unsigned)P.nbr_start[row + x1 + 1];
+    end = (unsigned)P.nbr_start[row + x1 + 1];
+}
+
+// The exact 5-NN of (qx, qy, qz) among the records [beg, end) of nbr_pts, merged into `top`.
+LIO_DEV void lio_knn_run(const LioIterParams& P, unsigned beg, unsigned end, float qx, float qy, float qz, LioTop5& top)
+{
     if (beg >= end) return;
     const lio_f2 QX = { qx, qx }, QY = { qy, qy }, QZ = { qz, qz };
     const float4* p = P.nbr_pts + beg;                     // float4 index == record index (2 float4 per pair)
@@ -314,6 +329,14 @@ LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, 
     }
     lio_knn_group(c0, c1, c2, c3, QX, QY, QZ, top);
 #endif
+}
+
+LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
+                            int cy, int cz, float Rx, LioTop5& top)
+{
+    unsigned beg, end;
+    lio_knn_range(P, g, qx, qy, qz, cy, cz, Rx, beg, end);
+    lio_knn_run(P, beg, end, qx, qy, qz, top);
 }
 
 // Association of one scan point from its five nearest map points (indices into the caller's map order):

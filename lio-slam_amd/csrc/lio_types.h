@@ -24,6 +24,13 @@ struct LioGrid {
     int32_t xs;         // x subdivision of the row buckets (1, 2, 4, 8)
     int32_t nxf;        // nx * xs
     float inv_cell_x;   // inv_cell * xs (exact: xs is a power of two)
+    // "Tight rows": a second set of replicated rows over the same points with k = 1 and a cell of tb_reach (+0.1 %), bucketed
+    // along x like the first and stored behind it in the same nbr_start / nbr_pts arrays.  A query whose search bound (the
+    // previous iteration's fifth neighbour + its own movement) is at most tb_reach walks its 3x3-cell row of THIS table: with
+    // tb_reach = 0.6 of the gate that is a (1.8 m)^2 cross-section instead of (2.5 m)^2 -- half the candidates, the same
+    // exact search.  tb_row0 = index of the table's first bucket in nbr_start; tb_reach < 0: no such table.
+    int32_t tb_row0, tb_ny, tb_nz;
+    float tb_oy, tb_oz, tb_inv_cell, tb_reach;
 };
 
 // Owner-computes predicate for a map sharded across GPUs: a scan

@@ -67,6 +67,7 @@ extern "C" void lio_s2m_default_config(lio_s2m_config* c)
     c->n_devices = 1;
     for (int i = 0; i < 8; ++i) c->device_ids[i] = i;
     c->x_sub = 0;
+    c->tight_rows = 0;
 }
 
 static void lio_fill_consts(lio_s2m_handle* h)
@@ -110,6 +111,7 @@ extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
     if (!(cfg->max_sq_dist > 0.0f)) return lio_fail(LIO_ERR_ARG, "max_sq_dist must be positive");
     if (cfg->x_sub != 0 && cfg->x_sub != 1 && cfg->x_sub != 2 && cfg->x_sub != 4 && cfg->x_sub != 8)
         return lio_fail(LIO_ERR_ARG, "cfg.x_sub must be 0 (auto), 1, 2, 4 or 8");
+    if (cfg->tight_rows < -1 || cfg->tight_rows > 1) return lio_fail(LIO_ERR_ARG, "cfg.tight_rows must be 0 (auto), 1 or -1");
     if (cfg->pipeline != 0 && cfg->pipeline != 1 && cfg->pipeline != 4)
         return lio_fail(LIO_ERR_ARG, "cfg.pipeline must be 0 (auto), 1 (one launch per iteration) or 4 (one-launch loop)");
     int ndev = 0;
@@ -252,13 +254,32 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
         cell *= 1.5f;   // larger cells keep the search exact, only less selective
     }
     g.xs = xsub; g.nxf = g.nx * xsub; g.inv_cell_x = g.inv_cell * (float)xsub;
+    // tight rows (LioGrid::tb_*): a second row table with k = 1 and a cell of `tight` x the gate radius, for the queries whose
+    // search bound is that small -- most of them from the second iteration on (cfg.tight_rows).  LIO_TIGHT = fraction of the
+    // gate radius (0 = off) in the environment for A/B runs: 0.5 / 0.6 / 0.7 measured within 1 % of each other.
+    float tight = (h->cfg.tight_rows > 0 || (h->cfg.tight_rows == 0 && h->cfg.max_batch >= 8)) ? 0.6f : 0.0f;
+    { const char* e = getenv("LIO_TIGHT"); if (e) { const float v = (float)atof(e); if (v == 0.0f || (v >= 0.2f && v <= 1.0f)) tight = v; } }
+    g.tb_row0 = 0; g.tb_ny = g.tb_nz = 0; g.tb_oy = g.tb_oz = 0.0f; g.tb_inv_cell = 0.0f; g.tb_reach = -1.0f;
+    size_t len_b = 0, rows_b = 0;
+    if (tight > 0.0f && (double)g.n_cells * xsub <= 64.0 * 1024.0 * 1024.0) {        // (a grid that large is mostly empty buckets already)
+        const float reach = sqrtf(h->cfg.max_sq_dist) * tight, cb = reach * 1.001f;
+        g.tb_inv_cell = 1.0f / cb;
+        g.tb_oy = mn[1] - 0.5f * cb; g.tb_oz = mn[2] - 0.5f * cb;
+        g.tb_ny = (int)floor(((double)mx[1] - g.tb_oy) * g.tb_inv_cell) + 2;
+        g.tb_nz = (int)floor(((double)mx[2] - g.tb_oz) * g.tb_inv_cell) + 2;
+        g.tb_row0 = g.n_cells * xsub;
+        g.tb_reach = reach;
+        rows_b = (size_t)g.tb_ny * g.tb_nz;
+        len_b = rows_b * g.nxf;
+    }
     h->grid = g;
-    HIPCHK(lio_grow(&h->d_cell_count, &h->cap_cell_count, (size_t)g.n_cells * (1 + xsub)));   // (point counts + neighbourhood-row bucket lengths)
+    const size_t len_a = (size_t)g.n_cells * xsub, reps = (size_t)((2 * g.k + 1) * (2 * g.k + 1)) + (len_b ? 9 : 0);
+    HIPCHK(lio_grow(&h->d_cell_count, &h->cap_cell_count, (size_t)g.n_cells + len_a + len_b));   // (point counts + row bucket lengths of both tables)
     HIPCHK(lio_grow(&h->d_cell_start, &h->cap_cell_start, (size_t)g.n_cells + 1));
-    HIPCHK(lio_grow(&h->d_nbr_start, &h->cap_nbr_start, (size_t)g.n_cells * xsub + 1));
-    HIPCHK(lio_grow(&h->d_nbr_pts, &h->cap_nbr_pts, nn * (size_t)((2 * g.k + 1) * (2 * g.k + 1)) + LIO_ROW_ALIGN * (size_t)g.ny * g.nz + 4 * LIO_ROW_ALIGN, 1.05));
-    HIPCHK(lio_grow(&h->d_tile_sums, &h->cap_tile_sums, 2 * ((size_t)lio_scan_tiles(g.n_cells * xsub) + 1)));   // (64-bit pair sums)
-    HIPCHK(lio_grow(&h->d_nbr_slot, &h->cap_nbr_slot, nn * (size_t)((2 * g.k + 1) * (2 * g.k + 1)), 1.05));
+    HIPCHK(lio_grow(&h->d_nbr_start, &h->cap_nbr_start, len_a + len_b + 1));
+    HIPCHK(lio_grow(&h->d_nbr_pts, &h->cap_nbr_pts, nn * reps + LIO_ROW_ALIGN * ((size_t)g.ny * g.nz + rows_b) + 4 * LIO_ROW_ALIGN, 1.05));
+    HIPCHK(lio_grow(&h->d_tile_sums, &h->cap_tile_sums, 2 * ((size_t)lio_scan_tiles((int)(len_a + len_b)) + 1)));   // (64-bit pair sums)
+    HIPCHK(lio_grow(&h->d_nbr_slot, &h->cap_nbr_slot, nn * reps, 1.05));
 
     HIPCHK(hipEventRecord(box ? h->ev_mapl[0] : h->ev_map[0], h->stream));
     if (n) {
@@ -266,7 +287,7 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
                              h->d_cell_start, h->d_tile_sums, h->d_sorted, h->d_nbr_start, h->d_nbr_pts, h->d_nbr_slot, h->cfg.use_lds != 0, h->stream);
     } else {
         HIPCHK(hipMemsetAsync(h->d_cell_start, 0, sizeof(int) * ((size_t)g.n_cells + 1), h->stream));
-        HIPCHK(hipMemsetAsync(h->d_nbr_start, 0, sizeof(int) * ((size_t)g.n_cells * xsub + 1), h->stream));
+        HIPCHK(hipMemsetAsync(h->d_nbr_start, 0, sizeof(int) * (len_a + len_b + 1), h->stream));
     }
     HIPCHK(hipEventRecord(box ? h->ev_mapl[1] : h->ev_map[1], h->stream));
     HIPCHK(hipGetLastError());

@@ -49,8 +49,36 @@ def test_random_plane_soup(pkg, oracle, seed):
     scan = (_planes(rng, 25, 300, 25.0, 0.05) ).astype(np.float32)
     scan = np.concatenate([scan, map_xyz[rng.choice(len(map_xyz), 2000)] + rng.normal(0, 0.05, (2000, 3)).astype(np.float32)])
     pose = np.concatenate([rng.normal(0, 0.02, 3), rng.normal(0, 0.1, 3)]).astype(np.float32)
-    n_acc, n_gate = _check(pkg, oracle, scan, map_xyz, pose, cell_div=1 + seed % 3, x_sub=(1, 4, 2, 8, 4, 1)[seed])
+    n_acc, n_gate = _check(pkg, oracle, scan, map_xyz, pose, cell_div=1 + seed % 3, x_sub=(1, 4, 2, 8, 4, 1)[seed], tight_rows=(1, 1, -1, 1, -1, 1)[seed])
     assert n_gate > 500
+
+
+@pytest.mark.parametrize("seed,cfg", [(20, dict(x_sub=4, tight_rows=1)), (21, dict(x_sub=8, tight_rows=1, cell_div=3)),
+                                      (22, dict(x_sub=1, tight_rows=1, pipeline=4)), (23, dict(x_sub=2, tight_rows=-1))])
+def test_later_iterations_on_plane_soup(pkg, oracle, seed, cfg):
+    """The search bound of the previous iteration picks the row table and the x range of a query from the second iteration
+    on (tight rows, finer x buckets): the correspondences of iteration 2 against the oracle's exact search, bit for bit,
+    on clouds with a wide spread of neighbour distances (so that both row tables are in use) and a pose that moves."""
+    rng = np.random.default_rng(seed)
+    map_xyz = _planes(rng, 20, 1200, 20.0, 0.02).astype(np.float32)
+    map_xyz = np.concatenate([map_xyz, rng.uniform(-20, 20, (3000, 3)).astype(np.float32)])          # sparse clutter: large d5
+    scan = np.concatenate([map_xyz[rng.choice(len(map_xyz), 3000)] + rng.normal(0, 0.04, (3000, 3)).astype(np.float32),
+                           _planes(rng, 10, 150, 20.0, 0.05).astype(np.float32)]).astype(np.float32)
+    pose = np.concatenate([rng.normal(0, 0.01, 3), rng.normal(0, 0.15, 3)]).astype(np.float32)
+    s2m = pkg.ScanToMap(record_corr_iter=2, max_iters=3, **cfg)
+    s2m.set_map(map_xyz)
+    p, res, rc = s2m.scan2MapOptimization(scan, pose)
+    flag, coeff, nn = s2m.get_correspondences(0)
+    s2m.close()
+    ocfg = oracle.default_config(knn_mode=1, n_threads=8, max_iters=3)
+    po, ro, _, corr = oracle.scan2map(ocfg, scan, map_xyz, pose, corr_iter=2)
+    assert rc == ro.status and res.iters == ro.iters == 3
+    np.testing.assert_array_equal(flag, corr[0])
+    np.testing.assert_array_equal(nn, corr[2])
+    np.testing.assert_array_equal(coeff.view(np.uint32)[flag == 1], corr[1].view(np.uint32)[flag == 1])
+    assert list(res.n_corr_iter)[:3] == list(ro.n_corr_iter)[:3]
+    assert int(flag.sum()) > 1000
+    np.testing.assert_allclose(p, po, rtol=0, atol=1e-5)
 
 
 def test_uniform_noise_rejects_most_planes(pkg, oracle):
@@ -72,7 +100,7 @@ def test_collinear_and_duplicate_neighbours(pkg, oracle):
     scan = np.concatenate([line[::3] + np.array([0.05, 0.02, 0.01], np.float32), dup[::6] + 0.01,
                            rng.normal(0, 0.1, (50, 3)).astype(np.float32), _planes(rng, 4, 100, 5.0, 0.03).astype(np.float32)])
     _check(pkg, oracle, scan.astype(np.float32), map_xyz, np.zeros(6, np.float32))
-    _check(pkg, oracle, scan.astype(np.float32), map_xyz, np.zeros(6, np.float32), x_sub=4)
+    _check(pkg, oracle, scan.astype(np.float32), map_xyz, np.zeros(6, np.float32), x_sub=4, tight_rows=1)
 
 
 @pytest.mark.parametrize("offset", [(5000.0, -3000.0, 120.0), (-65536.0, 131072.0, 0.0)])
@@ -88,7 +116,7 @@ def test_large_coordinates(pkg, oracle, offset):
     assert n_gate > 300
     # finer x buckets: at 131072 m one fp32 step is 1.6 cm, a fine cell (0.25 m / 4) holds four of them
     assert _check(pkg, oracle, scan, map_xyz, pose, x_sub=8, cell_div=3) == (n_acc, n_gate)
-    assert _check(pkg, oracle, scan, map_xyz, pose, x_sub=4) == (n_acc, n_gate)
+    assert _check(pkg, oracle, scan, map_xyz, pose, x_sub=4, tight_rows=1) == (n_acc, n_gate)
 
 
 def test_scan_partly_outside_the_map_and_nonfinite_points(pkg, oracle):
@@ -97,7 +125,7 @@ def test_scan_partly_outside_the_map_and_nonfinite_points(pkg, oracle):
     scan = np.concatenate([_planes(rng, 8, 200, 6.0, 0.04), rng.uniform(-500, 500, (500, 3)),
                            rng.uniform(1e6, 1e7, (20, 3))]).astype(np.float32)
     _check(pkg, oracle, scan, map_xyz, np.zeros(6, np.float32))
-    _check(pkg, oracle, scan, map_xyz, np.zeros(6, np.float32), x_sub=4)
+    _check(pkg, oracle, scan, map_xyz, np.zeros(6, np.float32), x_sub=4, tight_rows=1)
     # non-finite map points are ignored by both sides (they can never be within 1 m of anything)
     bad = map_xyz.copy()
     bad[::50] = np.nan

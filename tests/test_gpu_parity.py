@@ -67,10 +67,12 @@ def test_register_matches_oracle(pkg, oracle, small_case):
     dict(cell_div=1), dict(cell_div=2, cell_size=1.7), dict(cell_div=3, sort_scan=0),
     dict(x_sub=1), dict(x_sub=2), dict(x_sub=4), dict(x_sub=8, cell_div=3), dict(x_sub=4, cell_div=1, cell_size=2.5),
     dict(x_sub=4, use_lds=1, sort_scan=2), dict(x_sub=4, pipeline=4), dict(max_batch=64),
+    dict(tight_rows=1), dict(tight_rows=1, x_sub=4, pipeline=4), dict(tight_rows=1, x_sub=2, cell_div=3, cell_size=2.5),
+    dict(tight_rows=1, pipeline=1, sort_scan=0), dict(tight_rows=-1, max_batch=64),
 ])
 def test_kernel_variants_are_equivalent(pkg, oracle, small_case, variant):
     """LDS-staged vs global candidate scan, sorted vs caller-order scans, points
-    per thread, coarser grid, finer x buckets of the rows (x_sub; max_batch >= 8 picks 4): all exact searches -> identical
+    per thread, coarser grid, finer x buckets of the rows (x_sub; max_batch >= 8 picks 4), the tight second row table: all exact searches -> identical
     correspondences."""
     q = small_case["queries"][2]
     g, o = _run_both(pkg, oracle, q["scan"], small_case["map"], q["pose_init"], corr_iter=1, **variant)
