@@ -110,11 +110,14 @@ typedef struct lio_s2m_config {
                                 bucket table, +0.08 ms per map build.  0 = auto: 4 for a handle set up for batches
                                 (max_batch >= 8: the map is built once and searched by many scans), 1 for a node's handle
                                 (the map is rebuilt for every scan; a lone registration is latency-bound and gains nothing) */
-    int32_t tight_rows;      /* a second set of neighbourhood rows over the same points with 3x3 cells of 0.6 x the gate
-                                radius (+36 % map memory, +0.1 ms per map build): a query whose search bound -- the previous
-                                iteration's fifth neighbour plus its own movement -- is at most that walks a (1.8 m)^2
-                                cross-section instead of (2.5 m)^2; same results, -3 % per launch on the 512-scan batches.
-                                0 = auto (as x_sub: on for max_batch >= 8), 1 = on, -1 = off                              */
+    int32_t tight_rows;      /* further sets of neighbourhood rows over the same points with 3x3 cells of 0.6 / 0.3 / 0.15 x
+                                the gate radius (+36 % map memory and build time each): a query whose search bound -- the
+                                previous iteration's fifth neighbour plus its own movement -- is at most a table's cell walks
+                                that table's row: a (1.8 m)^2 / (0.9 m)^2 / (0.45 m)^2 cross-section instead of (2.5 m)^2 at
+                                the 1 m gate; same results.  -3 % per launch on the 512-scan batches of the default 0.5 m map
+                                (one table), 2.1x the registrations/s on a 0.1 m map (three).  1..3 = that many tables, -1 =
+                                none, 0 = auto: none for a node's handle (max_batch < 8), else one table plus the finer ones
+                                the map's point density has queries for (lio_s2m_profile.map_tight_tables says how many)  */
 } lio_s2m_config;
 
 /* What scan2MapOptimization leaves behind (MO:1817-1822 pose is returned in
@@ -151,6 +154,10 @@ typedef struct lio_s2m_profile {
     int32_t multi_exchange;    /* ... 0 = peer stores from a kernel, 1 = hipMemcpyPeerAsync, 2 = through host memory    */
     int32_t persist_fallbacks; /* one-launch loops of this handle that timed out at a barrier and were re-run through the
                                   launch loop inside the same call (cumulative; see lio_s2m_batch_results)              */
+    int32_t map_x_sub;         /* last set_map: x subdivision of the row buckets in effect (cfg.x_sub)                  */
+    int32_t map_tight_tables;  /* ... tight row tables built (cfg.tight_rows)                                            */
+    float   map_pts_per_cell;  /* ... map points per occupied grid cell, the density estimate behind the automatic choice
+                                  of map_tight_tables (0: not measured)                                                  */
 } lio_s2m_profile;
 
 typedef struct lio_s2m_handle lio_s2m_handle;

@@ -40,6 +40,7 @@ void lio_launch_map_bbox(const float* x, const float* y, const float* z, int n, 
 void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, const float* z, int n,
                           int* cell_of, int* cell_count, int* cell_start, int* tile_sums,
                           float4* sorted, int* nbr_start, float4* nbr_pts, int* nbr_slot, bool with_cell_sorted, hipStream_t s);
+void lio_launch_map_occupancy(const LioGrid& g, const float* x, const float* y, const float* z, int n, int* flags, hipStream_t s);
 int  lio_scan_tiles(int n_cells);
 void lio_launch_init_state(LioScanState* st, int n_scans, float* poses, bool from_state, const LioConsts& c,
                            int* n_active, hipStream_t s);

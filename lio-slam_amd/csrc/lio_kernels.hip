@@ -107,6 +107,21 @@ __global__ void k_map_cell_count(LioGrid g, const float* __restrict__ x, const f
     if (c >= 0 && cell_count) atomicAdd(&cell_count[c], 1);       // (the counts serve the cell-sorted copy of the LDS-staged variant only)
 }
 
+// Occupied cells of the grid (flags[0..n_cells) zeroed by the caller, the count lands in flags[n_cells]): points per occupied
+// cell is the density estimate that decides how many tight row tables a map is worth (lio_map_finish).
+__global__ void k_map_occupancy(LioGrid g, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n,
+                                int* __restrict__ flags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool first = false;
+    if (i < n) {
+        const int c = lio_map_cell(g, x[i], y[i], z[i]);
+        first = c >= 0 && atomicExch(&flags[c], 1) == 0;
+    }
+    const unsigned long long m = __ballot(first);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&flags[g.n_cells], __popcll(m));
+}
+
 // exclusive scan of cell_count[0..n) -> cell_start[0..n], three phases
 #define LIO_SCAN_ITEMS 16
 #define LIO_SCAN_TILE (256 * LIO_SCAN_ITEMS)
@@ -1112,10 +1127,16 @@ void lio_launch_exclusive_scan(const int* in, int n, int* tile_sums, int* out, h
 // cell_count: 2 x n_cells ints (point counts, then neighbourhood-row lengths; both reused as fill cursors);
 // tile_sums: 2 x (lio_scan_tiles(n_cells) + 1) ints, 8-byte aligned (one 64-bit pair sum per tile)
 // nbr_slot: n x (2k+1)^2 ints
-static LioGrid lio_tight_grid(const LioGrid& g)
+void lio_launch_map_occupancy(const LioGrid& g, const float* x, const float* y, const float* z, int n, int* flags, hipStream_t s)
+{
+    (void)hipMemsetAsync(flags, 0, sizeof(int) * ((size_t)g.n_cells + 1), s);
+    hipLaunchKernelGGL(k_map_occupancy, dim3((n + 255) / 256), dim3(256), 0, s, g, x, y, z, n, flags);
+}
+
+static LioGrid lio_tight_grid(const LioGrid& g, int l)
 {
     LioGrid b = g;                      // same x buckets; its own (y, z) cells, k = 1
-    b.oy = g.tb_oy; b.oz = g.tb_oz; b.inv_cell = g.tb_inv_cell; b.ny = g.tb_ny; b.nz = g.tb_nz; b.k = 1;
+    b.oy = g.tb_oy[l]; b.oz = g.tb_oz[l]; b.inv_cell = g.tb_inv_cell[l]; b.ny = g.tb_ny[l]; b.nz = g.tb_nz[l]; b.k = 1;
     return b;
 }
 
@@ -1125,42 +1146,47 @@ void lio_launch_map_build(const LioGrid& g, const float* x, const float* y, cons
 {
     const int nb = (n + 255) / 256;
     const int repsA = (2 * g.k + 1) * (2 * g.k + 1), repsB = 9;
-    const bool tight = g.tb_reach > 0.0f;
-    const LioGrid gb = lio_tight_grid(g);
-    const int lenA = g.n_cells * g.xs, lenB = tight ? g.tb_ny * g.tb_nz * g.nxf : 0;      // buckets of the two row tables
+    int n_tb = 0;
+    while (n_tb < LIO_TB_MAX && g.tb_reach[n_tb] > 0.0f) ++n_tb;
+    const int lenA = g.n_cells * g.xs;                                     // buckets of the grid's own rows
+    int len_all = lenA, rows_all = g.ny * g.nz;
+    for (int l = 0; l < n_tb; ++l) { len_all += g.tb_ny[l] * g.tb_nz[l] * g.nxf; rows_all += g.tb_ny[l] * g.tb_nz[l]; }
     const unsigned nbrA = (unsigned)(((long long)n * repsA + 255) / 256), nbrB = (unsigned)(((long long)n * repsB + 255) / 256);
     int* nbr_count = cell_count + g.n_cells;
-    int* slotB = nbr_slot + (size_t)n * repsA;
     unsigned long long* tiles64 = reinterpret_cast<unsigned long long*>(tile_sums);
     // with_cell_sorted: also the cell-sorted 1x copy + cell_start the LDS-staged variant (cfg.use_lds) walks; the default
     // candidate scan only needs the replicated rows, and a node rebuilds this for every scan: nothing it does not read
-    if (with_cell_sorted) (void)hipMemsetAsync(cell_count, 0, sizeof(int) * ((size_t)g.n_cells + lenA + lenB), s);
-    else (void)hipMemsetAsync(nbr_count, 0, sizeof(int) * ((size_t)lenA + lenB), s);
+    if (with_cell_sorted) (void)hipMemsetAsync(cell_count, 0, sizeof(int) * ((size_t)g.n_cells + len_all), s);
+    else (void)hipMemsetAsync(nbr_count, 0, sizeof(int) * (size_t)len_all, s);
     hipLaunchKernelGGL(k_map_cell_count, dim3(nb), dim3(256), 0, s, g, x, y, z, n, cell_of, with_cell_sorted ? cell_count : (int*)nullptr);
     hipLaunchKernelGGL(k_map_nbr_count, dim3(nbrA), dim3(256), 0, s, g, cell_of, x, y, z, n, nbr_count, nbr_slot);
     hipLaunchKernelGGL(k_map_nbr_pad_rows, dim3((g.ny * g.nz + 3) / 4), dim3(256), 0, s, g, nbr_count);
-    if (tight) {
-        hipLaunchKernelGGL(k_map_nbr_count, dim3(nbrB), dim3(256), 0, s, gb, cell_of, x, y, z, n, nbr_count + lenA, slotB);
-        hipLaunchKernelGGL(k_map_nbr_pad_rows, dim3((gb.ny * gb.nz + 3) / 4), dim3(256), 0, s, gb, nbr_count + lenA);
+    for (int l = 0; l < n_tb; ++l) {
+        const LioGrid gb = lio_tight_grid(g, l);
+        hipLaunchKernelGGL(k_map_nbr_count, dim3(nbrB), dim3(256), 0, s, gb, cell_of, x, y, z, n, nbr_count + g.tb_row0[l],
+                           nbr_slot + (size_t)n * (repsA + repsB * l));
+        hipLaunchKernelGGL(k_map_nbr_pad_rows, dim3((gb.ny * gb.nz + 3) / 4), dim3(256), 0, s, gb, nbr_count + g.tb_row0[l]);
     }
-    // one exclusive scan over the buckets of both tables: the tight rows' records follow the grid's own in nbr_pts
-    if (with_cell_sorted && g.xs == 1 && !tight) {
+    // one exclusive scan over the buckets of all tables: the tight rows' records follow the grid's own in nbr_pts
+    if (with_cell_sorted && g.xs == 1 && n_tb == 0) {
         // (one pass carrying both sums while the two tables have the same length)
         lio_launch_scan2<false>(cell_count, nbr_count, g.n_cells, tiles64, cell_start, nbr_start, s);
     } else {
         if (with_cell_sorted) lio_launch_exclusive_scan(cell_count, g.n_cells, tile_sums, cell_start, s);
-        lio_launch_exclusive_scan(nbr_count, lenA + lenB, tile_sums, nbr_start, s);
+        lio_launch_exclusive_scan(nbr_count, len_all, tile_sums, nbr_start, s);
     }
     if (with_cell_sorted) {
         (void)hipMemsetAsync(cell_count, 0, sizeof(int) * (size_t)g.n_cells, s);       // reused as the fill cursor of the cell-sorted copy
         hipLaunchKernelGGL(k_map_scatter, dim3(nb), dim3(256), 0, s, x, y, z, n, cell_of, cell_start, cell_count, sorted);
     }
     {
-        const int n_rec4 = n * (repsA + (tight ? repsB : 0)) + LIO_ROW_ALIGN * (g.ny * g.nz + (tight ? gb.ny * gb.nz : 0)) + 2 * LIO_ROW_ALIGN;   // + row and tail padding
+        const int n_rec4 = n * (repsA + repsB * n_tb) + LIO_ROW_ALIGN * rows_all + 2 * LIO_ROW_ALIGN;   // + row and tail padding
         hipLaunchKernelGGL(k_map_nbr_fill, dim3((n_rec4 + 255) / 256), dim3(256), 0, s, nbr_pts, n_rec4);
     }
     hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nbrA), dim3(256), 0, s, g, x, y, z, n, nbr_start, nbr_slot, nbr_pts);
-    if (tight) hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nbrB), dim3(256), 0, s, gb, x, y, z, n, nbr_start + lenA, slotB, nbr_pts);
+    for (int l = 0; l < n_tb; ++l)
+        hipLaunchKernelGGL(k_map_nbr_scatter, dim3(nbrB), dim3(256), 0, s, lio_tight_grid(g, l), x, y, z, n, nbr_start + g.tb_row0[l],
+                           nbr_slot + (size_t)n * (repsA + repsB * l), nbr_pts);
 }
 
 int lio_scan_tiles(int n_cells) { return (n_cells + LIO_SCAN_TILE - 1) / LIO_SCAN_TILE; }

@@ -263,12 +263,16 @@ LIO_DEV void lio_knn_range(const LioIterParams& P, const LioGrid& g, float qx, f
     beg = end = 0;
     if (x0 > x1) return;
     int row = (min(max(cz, 0), g.nz - 1) * g.ny + min(max(cy, 0), g.ny - 1)) * g.nxf;
-    if (Rx <= g.tb_reach) {
-        // tight rows (LioGrid::tb_*): every map point within Rx of the query lies in the 3x3 cells around the query's cell
-        // of the coarser-celled second table, i.e. in that cell's row; a query outside the grid is clamped as above
-        const int by = min(max(lio_cell_coord(qy, g.tb_oy, g.tb_inv_cell, g.tb_ny), 0), g.tb_ny - 1);
-        const int bz = min(max(lio_cell_coord(qz, g.tb_oz, g.tb_inv_cell, g.tb_nz), 0), g.tb_nz - 1);
-        row = g.tb_row0 + (bz * g.tb_ny + by) * g.nxf;
+    // tight rows (LioGrid::tb_*): every map point within Rx of the query lies in the 3x3 cells around the query's cell of a
+    // table whose cell is at least Rx, i.e. in that cell's row; the tightest such table wins (reach descending); a query
+    // outside the grid is clamped as above
+#pragma unroll
+    for (int l = 0; l < LIO_TB_MAX; ++l) {
+        if (Rx <= g.tb_reach[l]) {
+            const int by = min(max(lio_cell_coord(qy, g.tb_oy[l], g.tb_inv_cell[l], g.tb_ny[l]), 0), g.tb_ny[l] - 1);
+            const int bz = min(max(lio_cell_coord(qz, g.tb_oz[l], g.tb_inv_cell[l], g.tb_nz[l]), 0), g.tb_nz[l] - 1);
+            row = g.tb_row0[l] + (bz * g.tb_ny[l] + by) * g.nxf;
+        }
     }
 #if LIO_PREFETCH == 3
     beg = (unsigned)P.nbr_start[row + x0] & ~7u;

@@ -12,6 +12,7 @@
 // Hash grid over the voxel-downsampled local map (laserCloudSurfFromMapDS,
 // MO:149).  cell(v) = floor((v - origin) * inv_cell), linear id x-fastest so
 // that three x-adjacent cells are one contiguous run of sorted points.
+#define LIO_TB_MAX 3         // tight row tables per map (LioGrid::tb_*)
 struct LioGrid {
     float ox, oy, oz;
     float inv_cell;
@@ -24,13 +25,15 @@ struct LioGrid {
     int32_t xs;         // x subdivision of the row buckets (1, 2, 4, 8)
     int32_t nxf;        // nx * xs
     float inv_cell_x;   // inv_cell * xs (exact: xs is a power of two)
-    // "Tight rows": a second set of replicated rows over the same points with k = 1 and a cell of tb_reach (+0.1 %), bucketed
-    // along x like the first and stored behind it in the same nbr_start / nbr_pts arrays.  A query whose search bound (the
-    // previous iteration's fifth neighbour + its own movement) is at most tb_reach walks its 3x3-cell row of THIS table: with
-    // tb_reach = 0.6 of the gate that is a (1.8 m)^2 cross-section instead of (2.5 m)^2 -- half the candidates, the same
-    // exact search.  tb_row0 = index of the table's first bucket in nbr_start; tb_reach < 0: no such table.
-    int32_t tb_row0, tb_ny, tb_nz;
-    float tb_oy, tb_oz, tb_inv_cell, tb_reach;
+    // "Tight rows": up to LIO_TB_MAX further sets of replicated rows over the same points, each with k = 1 and a cell of
+    // tb_reach[l] (+0.1 %), bucketed along x like the first and stored behind it in the same nbr_start / nbr_pts arrays,
+    // tb_reach descending (0.6, 0.3, 0.15 of the gate radius).  A query whose search bound (the previous iteration's fifth
+    // neighbour + its own movement) is at most tb_reach[l] walks its 3x3-cell row of THAT table, the tightest one that
+    // holds its bound: at 0.6 of a 1 m gate a (1.8 m)^2 cross-section instead of (2.5 m)^2, at 0.3 (0.9 m)^2 -- the same
+    // exact search over a fraction of the candidates.  tb_row0[l] = index of the table's first bucket in nbr_start;
+    // tb_reach[l] < 0: no such table.
+    int32_t tb_row0[LIO_TB_MAX], tb_ny[LIO_TB_MAX], tb_nz[LIO_TB_MAX];
+    float tb_oy[LIO_TB_MAX], tb_oz[LIO_TB_MAX], tb_inv_cell[LIO_TB_MAX], tb_reach[LIO_TB_MAX];
 };
 
 // Owner-computes predicate for a map sharded across GPUs: a scan

@@ -111,7 +111,7 @@ extern "C" int lio_s2m_create(const lio_s2m_config* cfg, lio_s2m_handle** out)
     if (!(cfg->max_sq_dist > 0.0f)) return lio_fail(LIO_ERR_ARG, "max_sq_dist must be positive");
     if (cfg->x_sub != 0 && cfg->x_sub != 1 && cfg->x_sub != 2 && cfg->x_sub != 4 && cfg->x_sub != 8)
         return lio_fail(LIO_ERR_ARG, "cfg.x_sub must be 0 (auto), 1, 2, 4 or 8");
-    if (cfg->tight_rows < -1 || cfg->tight_rows > 1) return lio_fail(LIO_ERR_ARG, "cfg.tight_rows must be 0 (auto), 1 or -1");
+    if (cfg->tight_rows < -1 || cfg->tight_rows > LIO_TB_MAX) return lio_fail(LIO_ERR_ARG, "cfg.tight_rows must be -1 (none), 0 (auto) or 1..3 tables");
     if (cfg->pipeline != 0 && cfg->pipeline != 1 && cfg->pipeline != 4)
         return lio_fail(LIO_ERR_ARG, "cfg.pipeline must be 0 (auto), 1 (one launch per iteration) or 4 (one-launch loop)");
     int ndev = 0;
@@ -254,26 +254,63 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
         cell *= 1.5f;   // larger cells keep the search exact, only less selective
     }
     g.xs = xsub; g.nxf = g.nx * xsub; g.inv_cell_x = g.inv_cell * (float)xsub;
-    // tight rows (LioGrid::tb_*): a second row table with k = 1 and a cell of `tight` x the gate radius, for the queries whose
-    // search bound is that small -- most of them from the second iteration on (cfg.tight_rows).  LIO_TIGHT = fraction of the
-    // gate radius (0 = off) in the environment for A/B runs: 0.5 / 0.6 / 0.7 measured within 1 % of each other.
-    float tight = (h->cfg.tight_rows > 0 || (h->cfg.tight_rows == 0 && h->cfg.max_batch >= 8)) ? 0.6f : 0.0f;
-    { const char* e = getenv("LIO_TIGHT"); if (e) { const float v = (float)atof(e); if (v == 0.0f || (v >= 0.2f && v <= 1.0f)) tight = v; } }
-    g.tb_row0 = 0; g.tb_ny = g.tb_nz = 0; g.tb_oy = g.tb_oz = 0.0f; g.tb_inv_cell = 0.0f; g.tb_reach = -1.0f;
+    // tight rows (LioGrid::tb_*, cfg.tight_rows): further row tables with k = 1 and cells of 0.6 / 0.3 / 0.15 x the gate radius
+    // for the queries whose search bound is that small -- most of them from the second iteration on.  LIO_TIGHT = a comma
+    // separated, descending list of fractions (0 = none) in the environment for A/B runs.
+    float frac[LIO_TB_MAX] = { 0.6f, 0.3f, 0.15f };
+    int n_tb = h->cfg.tight_rows > 0 ? std::min(h->cfg.tight_rows, LIO_TB_MAX) : 0;
+    float pts_per_cell = 0.0f;
+    if (h->cfg.tight_rows == 0 && h->cfg.max_batch >= 8) {
+        // auto, a handle set up for batches: one table always; the finer ones where the map is dense enough to have queries for
+        // them.  Points per occupied cell -> point spacing on the surfaces, s = cell / sqrt(points per cell); the fifth neighbour
+        // of a query on such a surface is about 1.26 s away; a table is built when its reach is at least that.  (Measured on
+        // the parameter sets of tools/param_sets.sh: the sparse 0.5 m maps are fastest with one table -- a second one only adds
+        // build time --, the 0.1 m map with three: +39 % registrations/s over one.)  Costs one small kernel and a 4-byte
+        // read-back here; a map whose bounding box is still on the device (`box`) stays asynchronous and gets one table.
+        n_tb = 1;
+        if (!box && n > 0) {
+            HIPCHK(lio_grow(&h->d_cell_count, &h->cap_cell_count, (size_t)g.n_cells + 1));
+            lio_launch_map_occupancy(g, h->d_mx, h->d_my, h->d_mz, (int)n, h->d_cell_count, h->stream);
+            int occ = 0;
+            HIPCHK(hipMemcpyAsync(&occ, h->d_cell_count + g.n_cells, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (occ > 0) {
+                pts_per_cell = (float)n / (float)occ;
+                const float spacing = cell / sqrtf(pts_per_cell);
+                while (n_tb < LIO_TB_MAX && sqrtf(h->cfg.max_sq_dist) * frac[n_tb] >= 1.26f * spacing) ++n_tb;
+            }
+        }
+    }
+    if (const char* e = getenv("LIO_TIGHT")) {
+        n_tb = 0;
+        for (const char* p = e; *p && n_tb < LIO_TB_MAX;) {
+            char* q = nullptr;
+            const float v = strtof(p, &q);
+            if (q == p) break;
+            if (v >= 0.05f && v <= 1.0f && (n_tb == 0 || v < frac[n_tb - 1])) frac[n_tb++] = v;
+            p = (*q == ',') ? q + 1 : q;
+            if (*q != ',') break;
+        }
+    }
+    if ((double)g.n_cells * xsub > 64.0 * 1024.0 * 1024.0) n_tb = 0;        // (a grid that large is mostly empty buckets already)
     size_t len_b = 0, rows_b = 0;
-    if (tight > 0.0f && (double)g.n_cells * xsub <= 64.0 * 1024.0 * 1024.0) {        // (a grid that large is mostly empty buckets already)
-        const float reach = sqrtf(h->cfg.max_sq_dist) * tight, cb = reach * 1.001f;
-        g.tb_inv_cell = 1.0f / cb;
-        g.tb_oy = mn[1] - 0.5f * cb; g.tb_oz = mn[2] - 0.5f * cb;
-        g.tb_ny = (int)floor(((double)mx[1] - g.tb_oy) * g.tb_inv_cell) + 2;
-        g.tb_nz = (int)floor(((double)mx[2] - g.tb_oz) * g.tb_inv_cell) + 2;
-        g.tb_row0 = g.n_cells * xsub;
-        g.tb_reach = reach;
-        rows_b = (size_t)g.tb_ny * g.tb_nz;
-        len_b = rows_b * g.nxf;
+    for (int l = 0; l < LIO_TB_MAX; ++l) {
+        g.tb_row0[l] = 0; g.tb_ny[l] = g.tb_nz[l] = 0; g.tb_oy[l] = g.tb_oz[l] = 0.0f; g.tb_inv_cell[l] = 0.0f; g.tb_reach[l] = -1.0f;
+        if (l >= n_tb) continue;
+        const float reach = sqrtf(h->cfg.max_sq_dist) * frac[l], cb = reach * 1.001f;
+        const float inv = 1.0f / cb, oy = mn[1] - 0.5f * cb, oz = mn[2] - 0.5f * cb;
+        const double ny = floor(((double)mx[1] - oy) * inv) + 2.0, nz = floor(((double)mx[2] - oz) * inv) + 2.0;
+        // (bucket indices stay far inside 31 bits, and so do record offsets: every table adds 9 records per point + row padding)
+        const double recs = (double)nn * ((2 * g.k + 1) * (2 * g.k + 1) + 9.0 * (l + 1)) + LIO_ROW_ALIGN * ((double)g.ny * g.nz + (double)rows_b + ny * nz);
+        if ((double)g.n_cells * xsub + (double)len_b + ny * nz * g.nxf > 192.0 * 1024.0 * 1024.0 || recs > 2040.0 * 1024.0 * 1024.0) { n_tb = l; continue; }
+        g.tb_inv_cell[l] = inv; g.tb_oy[l] = oy; g.tb_oz[l] = oz; g.tb_ny[l] = (int)ny; g.tb_nz[l] = (int)nz;
+        g.tb_row0[l] = (int)((size_t)g.n_cells * xsub + len_b);
+        g.tb_reach[l] = reach;
+        rows_b += (size_t)g.tb_ny[l] * g.tb_nz[l];
+        len_b += (size_t)g.tb_ny[l] * g.tb_nz[l] * g.nxf;
     }
     h->grid = g;
-    const size_t len_a = (size_t)g.n_cells * xsub, reps = (size_t)((2 * g.k + 1) * (2 * g.k + 1)) + (len_b ? 9 : 0);
+    const size_t len_a = (size_t)g.n_cells * xsub, reps = (size_t)((2 * g.k + 1) * (2 * g.k + 1)) + 9 * (size_t)n_tb;
     HIPCHK(lio_grow(&h->d_cell_count, &h->cap_cell_count, (size_t)g.n_cells + len_a + len_b));   // (point counts + row bucket lengths of both tables)
     HIPCHK(lio_grow(&h->d_cell_start, &h->cap_cell_start, (size_t)g.n_cells + 1));
     HIPCHK(lio_grow(&h->d_nbr_start, &h->cap_nbr_start, len_a + len_b + 1));
@@ -305,6 +342,9 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
     h->prof.map_upload_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
     h->prof.n_map = (int64_t)n;
     h->prof.n_cells = g.n_cells;
+    h->prof.map_x_sub = g.xs;
+    h->prof.map_tight_tables = n_tb;
+    h->prof.map_pts_per_cell = pts_per_cell;
     h->n_map = n;
     h->has_map = true;
     h->graph_dirty = true;

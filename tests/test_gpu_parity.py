@@ -69,6 +69,7 @@ def test_register_matches_oracle(pkg, oracle, small_case):
     dict(x_sub=4, use_lds=1, sort_scan=2), dict(x_sub=4, pipeline=4), dict(max_batch=64),
     dict(tight_rows=1), dict(tight_rows=1, x_sub=4, pipeline=4), dict(tight_rows=1, x_sub=2, cell_div=3, cell_size=2.5),
     dict(tight_rows=1, pipeline=1, sort_scan=0), dict(tight_rows=-1, max_batch=64),
+    dict(tight_rows=2, x_sub=4), dict(tight_rows=3, x_sub=4, pipeline=4), dict(tight_rows=3, x_sub=1, cell_div=1),
 ])
 def test_kernel_variants_are_equivalent(pkg, oracle, small_case, variant):
     """LDS-staged vs global candidate scan, sorted vs caller-order scans, points
@@ -248,3 +249,48 @@ def test_degeneracy_chain_is_bit_exact_on_many_normal_matrices(pkg, oracle, synt
             assert np.array_equal(np.array(res.matP, np.float32).view(np.uint32), np.asarray(matP_o, np.float32).reshape(-1).view(np.uint32))
             assert np.array_equal(np.array(res.AtA, np.float32).view(np.uint32), np.array(res_o.AtA, np.float32).view(np.uint32))
     assert n_deg >= 2
+
+
+def test_row_tables_follow_the_handle_and_the_map_density(pkg, oracle, small_case):
+    """cfg.x_sub / cfg.tight_rows = auto: a node's handle (max_batch < 8) keeps the plain rows, a batch handle gets x buckets four
+    times finer and one tight table, plus the finer tables when the map is dense enough to have queries for them -- and the
+    results do not depend on any of it."""
+    q = small_case["queries"][0]
+    got = []
+    for cfg in (dict(), dict(max_batch=64), dict(max_batch=64, tight_rows=-1, x_sub=1)):
+        s2m = pkg.ScanToMap(**cfg)
+        s2m.set_map(small_case["map"])
+        pose, res, rc = s2m.scan2MapOptimization(q["scan"], q["pose_init"])
+        prof = s2m.profile()
+        got.append((pose.copy(), res.iters, prof.map_x_sub, prof.map_tight_tables, prof.map_pts_per_cell))
+        s2m.close()
+    assert got[0][2:4] == (1, 0) and got[0][4] == 0.0
+    assert got[1][2] == 4 and got[1][3] >= 1 and got[1][4] > 1.0
+    assert got[2][2:4] == (1, 0)
+    for g in got[1:]:
+        assert np.array_equal(g[0].view(np.uint32), got[0][0].view(np.uint32)) and g[1] == got[0][1]
+    # a dense map (2 cm spacing on a few planes): all three tables
+    rng = np.random.default_rng(5)
+    u = np.stack(np.meshgrid(np.arange(0, 6, 0.03), np.arange(0, 6, 0.03)), -1).reshape(-1, 2).astype(np.float32)
+    planes = [np.concatenate([u, np.full((len(u), 1), z, np.float32)], 1) for z in (0.0, 2.5)]
+    planes.append(np.concatenate([u[:, :1], np.full((len(u), 1), 6.0, np.float32), u[:, 1:] * 0.4], 1))
+    dense = (np.concatenate(planes) + rng.normal(0, 0.004, (3 * len(u), 3))).astype(np.float32)
+    scan = (dense[rng.choice(len(dense), 4000, replace=False)] + rng.normal(0, 0.01, (4000, 3))).astype(np.float32)
+    pose0 = np.array([0.004, -0.003, 0.005, 0.03, -0.02, 0.025], np.float32)
+    ref = None
+    for cfg in (dict(max_batch=64), dict(tight_rows=-1, x_sub=1)):
+        s2m = pkg.ScanToMap(record_corr_iter=2, **cfg)
+        s2m.set_map(dense)
+        pose, res, rc = s2m.scan2MapOptimization(scan, pose0)
+        corr = s2m.get_correspondences(0)
+        prof = s2m.profile()
+        s2m.close()
+        if ref is None:
+            assert prof.map_tight_tables == 3 and prof.map_pts_per_cell > 50
+            ref = (pose, res.iters, corr)
+        else:
+            assert prof.map_tight_tables == 0
+            assert np.array_equal(pose.view(np.uint32), ref[0].view(np.uint32)) and res.iters == ref[1]
+            for a, b in zip(corr, ref[2]):
+                assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    assert ref[1] >= 3
