@@ -597,7 +597,7 @@ def main():
         },
         "roofline_issue": issue,
         "map_build_ms": prof0.map_build_ms, "map_upload_ms": prof0.map_upload_ms,
-        "map_rows": {"x_sub": prof0.map_x_sub, "tight_tables": prof0.map_tight_tables, "points_per_occupied_cell": round(prof0.map_pts_per_cell, 2)},
+        "map_rows": {"x_sub": prof0.map_x_sub, "tight_tables": prof0.map_tight_tables, "first_try": prof0.map_first_try, "points_per_occupied_cell": round(prof0.map_pts_per_cell, 2)},
         "grid_cells": int(prof0.n_cells),
     }
 

@@ -156,6 +156,8 @@ typedef struct lio_s2m_profile {
                                   launch loop inside the same call (cumulative; see lio_s2m_batch_results)              */
     int32_t map_x_sub;         /* last set_map: x subdivision of the row buckets in effect (cfg.x_sub)                  */
     int32_t map_tight_tables;  /* ... tight row tables built (cfg.tight_rows)                                            */
+    int32_t map_first_try;     /* ... the tight table a query without a search bound tries before the full search (its
+                                  index, 0 = the widest; -1: none -- the full search at once)                            */
     float   map_pts_per_cell;  /* ... map points per occupied grid cell, the density estimate behind the automatic choice
                                   of map_tight_tables (0: not measured)                                                  */
 } lio_s2m_profile;

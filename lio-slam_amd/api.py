@@ -56,7 +56,7 @@ class S2MProfile(C.Structure):
         ("n_map", C.c_int64), ("n_cells", C.c_int64),
         ("pipeline", C.c_int32), ("multi_iterations", C.c_int32), ("multi_stream_syncs", C.c_int32),
         ("multi_event_waits", C.c_int32), ("multi_exchange", C.c_int32), ("persist_fallbacks", C.c_int32),
-        ("map_x_sub", C.c_int32), ("map_tight_tables", C.c_int32), ("map_pts_per_cell", C.c_float),
+        ("map_x_sub", C.c_int32), ("map_tight_tables", C.c_int32), ("map_first_try", C.c_int32), ("map_pts_per_cell", C.c_float),
     ]
 
 

@@ -983,6 +983,7 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
         // R ~ 0.5 m against the 1 m gate: half the candidate run.  One float per point is kept.
         float bound2 = P.c.max_sq_dist;
         float Rx = sqrtf(P.c.max_sq_dist) * 1.0001f + 1e-6f;          // reach along x: the gate, unless the bound below is tighter
+        bool bounded = false;
         const int ci = base + bd.first + pp * LIO_BLOCK + (int)threadIdx.x;   // slot in the batch SoA
         if (use_cache && act[pp]) {
             const float d5 = P.d5_cache[ci];
@@ -993,7 +994,7 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
                 const float mv = sqrtf(lio_sqdist(qx[pp], qy[pp], qz[pp], ox, oy, oz));
                 const float R = (sqrtf(d5) + mv) * 1.0001f + 1e-6f;
                 const float r2 = R * R * 1.0001f;
-                if (r2 < bound2) { bound2 = r2; Rx = R; }
+                if (r2 < bound2) { bound2 = r2; Rx = R; bounded = true; }
             }
         }
         // (d2 == bound2 with any real index sorts below the sentinel, so ties at the bound are kept)
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(LIO_BLOCK, (PPT == 1 && !STAGE && !CORNER) ? LIO_MI
                 lio_knn_lds(s_pts, s_cell, rxn1, ryn, rx0, ry0, rz0, ry1, rz1, g.nx, g.k,
                             qx[pp], qy[pp], qz[pp], cx[pp], cy[pp], cz[pp], top);
             else
-                lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cy[pp], cz[pp], Rx, top);
+                lio_knn_global(P, g, qx[pp], qy[pp], qz[pp], cy[pp], cz[pp], Rx, bound2, bounded, top);
         }
         int nn[5] = { lio_key_idx(top.k0), lio_key_idx(top.k1), lio_key_idx(top.k2), lio_key_idx(top.k3), lio_key_idx(top.k4) };
         const float d2_5 = lio_key_d2(top.k4);

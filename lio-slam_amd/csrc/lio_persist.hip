@@ -154,6 +154,7 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
         // ---- exact 5-NN (MO:1631) inside the search bound of the previous iteration (see k_s2m_iterate)
         float bound2 = P.c.max_sq_dist;
         float Rx = sqrtf(P.c.max_sq_dist) * 1.0001f + 1e-6f;              // reach along x: the gate, unless the bound below is tighter
+        bool bounded = false;
         if (use_cache && act) {
             const float d5 = P.d5_cache[ci];
             if (d5 >= 0.0f) {
@@ -163,12 +164,12 @@ __global__ __launch_bounds__(LIO_BLOCK, 2) void k_s2m_persist(LioIterParams P, u
                 const float mv = sqrtf(lio_sqdist(qx, qy, qz, ox, oy, oz));
                 const float R = (sqrtf(d5) + mv) * 1.0001f + 1e-6f;
                 const float r2 = R * R * 1.0001f;
-                if (r2 < bound2) { bound2 = r2; Rx = R; }
+                if (r2 < bound2) { bound2 = r2; Rx = R; bounded = true; }
             }
         }
         const double sentinel = lio_make_key(bound2, -1);
         LioTop5 top = { sentinel, sentinel, sentinel, sentinel, sentinel };
-        if (act) lio_knn_global(P, g, qx, qy, qz, cy, cz, Rx, top);
+        if (act) lio_knn_global(P, g, qx, qy, qz, cy, cz, Rx, bound2, bounded, top);
         const bool ok = act && (lio_key_d2(top.k4) < P.c.max_sq_dist);       // gate MO:1641
         const int nn[5] = { lio_key_idx(top.k0), lio_key_idx(top.k1), lio_key_idx(top.k2), lio_key_idx(top.k3), lio_key_idx(top.k4) };
         if (P.d5_cache && inr) P.d5_cache[ci] = ok ? lio_key_d2(top.k4) : -1.0f;

@@ -335,12 +335,29 @@ LIO_DEV void lio_knn_run(const LioIterParams& P, unsigned beg, unsigned end, flo
 #endif
 }
 
+// The exact 5-NN of one query over the replicated rows.  (Rx, bound2): the search radius and the sentinel's squared distance --
+// the gate, or (`bounded`) the tighter pair the previous iteration's neighbours gave.  An unbounded query on a dense map goes
+// through the tight tables first (LioGrid::tb_try): one copy of the candidate loop serves every round.
 LIO_DEV void lio_knn_global(const LioIterParams& P, const LioGrid& g, float qx, float qy, float qz,
-                            int cy, int cz, float Rx, LioTop5& top)
+                            int cy, int cz, float Rx, float bound2, bool bounded, LioTop5& top)
 {
-    unsigned beg, end;
-    lio_knn_range(P, g, qx, qy, qz, cy, cz, Rx, beg, end);
-    lio_knn_run(P, beg, end, qx, qy, qz, top);
+    int lvl = bounded ? -1 : g.tb_try;
+    for (;;) {
+        float rx = Rx, b2 = bound2;
+        if (lvl >= 0) {
+            rx = lvl == 2 ? g.tb_reach[2] : (lvl == 1 ? g.tb_reach[1] : g.tb_reach[0]);
+            b2 = lvl == 2 ? g.tb_try_b2[2] : (lvl == 1 ? g.tb_try_b2[1] : g.tb_try_b2[0]);
+        }
+        // (d2 == b2 with any real index sorts below the sentinel, so ties at the bound are kept)
+        const double sentinel = lio_make_key(b2, -1);                     // index 0xffffffff: above every real index
+        top.k0 = top.k1 = top.k2 = top.k3 = top.k4 = sentinel;
+        unsigned beg, end;
+        lio_knn_range(P, g, qx, qy, qz, cy, cz, rx, beg, end);
+        lio_knn_run(P, beg, end, qx, qy, qz, top);
+        // five points within the tried radius: every point outside the table's row is farther than that -- done
+        if (lvl < 0 || lio_key_idx(top.k4) != -1) break;
+        --lvl;
+    }
 }
 
 // Association of one scan point from its five nearest map points (indices into the caller's map order):

@@ -34,6 +34,13 @@ struct LioGrid {
     // tb_reach[l] < 0: no such table.
     int32_t tb_row0[LIO_TB_MAX], tb_ny[LIO_TB_MAX], tb_nz[LIO_TB_MAX];
     float tb_oy[LIO_TB_MAX], tb_oz[LIO_TB_MAX], tb_inv_cell[LIO_TB_MAX], tb_reach[LIO_TB_MAX];
+    // Progressive search of a query WITHOUT a bound (first iteration; a point that failed the gate last time): on a map dense
+    // enough that its fifth neighbour is almost surely within tb_reach[tb_try], that table is tried first with the
+    // acceptance bound tb_try_b2[l] = (tb_reach[l] / 1.0002)^2 -- five points inside it prove that nothing outside the
+    // table's row can be closer --, then the coarser tables, then the full search at the gate.  tb_try < 0: the full search
+    // at once (sparse maps: nearly every wave would pay both).
+    int32_t tb_try;
+    float tb_try_b2[LIO_TB_MAX];
 };
 
 // Owner-computes predicate for a map sharded across GPUs: a scan

@@ -4,6 +4,8 @@ Bar (SURVEY 8c / north_star): correspondence flags, neighbour index sets and
 plane coefficients BIT-EXACT per iteration-0 association; iteration count,
 convergence and degeneracy flags equal; final pose within POSE_TOL.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -251,6 +253,7 @@ def test_degeneracy_chain_is_bit_exact_on_many_normal_matrices(pkg, oracle, synt
     assert n_deg >= 2
 
 
+@pytest.mark.skipif(any(os.environ.get(k) for k in ("LIO_TIGHT", "LIO_X_SUB", "LIO_TRY")), reason="the A/B overrides replace the automatic choice")
 def test_row_tables_follow_the_handle_and_the_map_density(pkg, oracle, small_case):
     """cfg.x_sub / cfg.tight_rows = auto: a node's handle (max_batch < 8) keeps the plain rows, a batch handle gets x buckets four
     times finer and one tight table, plus the finer tables when the map is dense enough to have queries for them -- and the
@@ -275,22 +278,32 @@ def test_row_tables_follow_the_handle_and_the_map_density(pkg, oracle, small_cas
     planes = [np.concatenate([u, np.full((len(u), 1), z, np.float32)], 1) for z in (0.0, 2.5)]
     planes.append(np.concatenate([u[:, :1], np.full((len(u), 1), 6.0, np.float32), u[:, 1:] * 0.4], 1))
     dense = (np.concatenate(planes) + rng.normal(0, 0.004, (3 * len(u), 3))).astype(np.float32)
-    scan = (dense[rng.choice(len(dense), 4000, replace=False)] + rng.normal(0, 0.01, (4000, 3))).astype(np.float32)
+    # ... and a query without a bound tries the finest table first, then the coarser ones, then the full search: scan points on
+    # the planes (found at once), 0.1-0.5 m off them (found one or two tables up) and metres away (every table fails, then the gate)
+    scan = np.concatenate([dense[rng.choice(len(dense), 4000, replace=False)] + rng.normal(0, 0.01, (4000, 3)),
+                           dense[rng.choice(len(dense), 600, replace=False)] + rng.uniform(0.1, 0.5, (600, 1)) * np.array([0.0, 0.0, 1.0]),
+                           rng.uniform(-4, 10, (200, 3))]).astype(np.float32)
     pose0 = np.array([0.004, -0.003, 0.005, 0.03, -0.02, 0.025], np.float32)
-    ref = None
-    for cfg in (dict(max_batch=64), dict(tight_rows=-1, x_sub=1)):
-        s2m = pkg.ScanToMap(record_corr_iter=2, **cfg)
-        s2m.set_map(dense)
-        pose, res, rc = s2m.scan2MapOptimization(scan, pose0)
-        corr = s2m.get_correspondences(0)
-        prof = s2m.profile()
-        s2m.close()
-        if ref is None:
-            assert prof.map_tight_tables == 3 and prof.map_pts_per_cell > 50
-            ref = (pose, res.iters, corr)
-        else:
-            assert prof.map_tight_tables == 0
+    for corr_iter in (0, 2):
+        ref = None
+        for cfg in (dict(max_batch=64), dict(tight_rows=-1, x_sub=1), dict(max_batch=64, pipeline=4)):
+            s2m = pkg.ScanToMap(record_corr_iter=corr_iter, **cfg)
+            s2m.set_map(dense)
+            pose, res, rc = s2m.scan2MapOptimization(scan, pose0)
+            corr = s2m.get_correspondences(0)
+            prof = s2m.profile()
+            s2m.close()
+            if ref is None:
+                assert prof.map_tight_tables == 3 and prof.map_first_try == 2 and prof.map_pts_per_cell > 50
+                ref = (pose, res.iters, corr)
+                continue
+            assert prof.map_tight_tables == (0 if cfg.get("tight_rows") == -1 else 3)
             assert np.array_equal(pose.view(np.uint32), ref[0].view(np.uint32)) and res.iters == ref[1]
             for a, b in zip(corr, ref[2]):
                 assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
-    assert ref[1] >= 3
+        assert ref[1] >= 3
+        # the oracle's exact search agrees (flags and neighbour sets of the recorded iteration)
+        ocfg = oracle.default_config(knn_mode=1, n_threads=8)
+        _, res_o, _, corr_o = oracle.scan2map(ocfg, scan, dense, pose0, corr_iter=corr_iter)
+        assert res_o.iters == ref[1]
+        assert np.array_equal(ref[2][0], corr_o[0]) and np.array_equal(ref[2][2], corr_o[2])
