@@ -23,6 +23,8 @@ def main():
         print(f"{tag}: no bench line ({e})")
         return
     c, r = j["config"], j["roofline"]
+    rows = j.get("map_rows", {})
+    kdiv, tables = c.get("kernel", {}).get("cell_div", 2), rows.get("tight_tables", 0)
     hit, miss = avg(os.path.join(d, f"pmc_TCC_{tag}.txt"), "TCC_HIT_sum"), avg(os.path.join(d, f"pmc_TCC_{tag}.txt"), "TCC_MISS_sum")
     fs, ws = avg(os.path.join(d, f"pmc_FETCH_{tag}.txt"), "FETCH_SIZE"), avg(os.path.join(d, f"pmc_FETCH_{tag}.txt"), "WRITE_SIZE")
     kt = None
@@ -35,7 +37,8 @@ def main():
     traffic = (2 * fs + ws) * 1024 if fs is not None and ws is not None else None      # KB -> bytes, gfx950 FETCH_SIZE correction x2
     out = {
         "set": tag, "leaf_scan": c["mappingSurfLeafSize"], "leaf_map": c["surroundingKeyframeMapLeafSize"], "scans_per_step": c["scans_per_step"],
-        "N_s_mean": round(c["N_s_mean"]), "N_m": c["N_m"], "rows_MB": round(c["N_m"] * 25 * 16 / 1e6, 1), "gn_iters_mean": round(c["gn_iters_mean"], 2),
+        "N_s_mean": round(c["N_s_mean"]), "N_m": c["N_m"], "rows_MB": round(c["N_m"] * ((2 * kdiv + 1) ** 2 + 9 * tables) * 16 / 1e6, 1), "x_sub": rows.get("x_sub"), "tight_tables": tables, "first_try": rows.get("first_try"),
+        "points_per_occupied_cell": rows.get("points_per_occupied_cell"), "gn_iters_mean": round(c["gn_iters_mean"], 2),
         "value_reg_per_s": round(j["value"]), "ms_per_step": round(j["ms_per_step"], 3),
         "ms_per_launch_hip_events": round(r["ms_per_launch"], 4), "ms_per_launch_rocprofv3": round(kt[1] / 1e3, 4) if kt else None,
         "algorithmic_MB_per_launch": round(r["algorithmic_bytes_per_launch"] / 1e6, 2), "frac_hbm": round(r["frac"], 4),
