@@ -216,6 +216,9 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
 {
     const size_t nn = n ? n : 1;
     float mn[3], mx[3];
+    // (a box that is not finite -- a keyframe cloud of nothing but non-finite points -- is ignored: the box is then computed here)
+    for (int a = 0; a < 3 && box; ++a)
+        if (!(box[a] <= box[3 + a]) || !(fabsf(box[a]) <= 1.0e15f) || !(fabsf(box[3 + a]) <= 1.0e15f)) box = nullptr;   // (LIO_MAX_COORD)
     if (box) {
         for (int a = 0; a < 3; ++a) { mn[a] = n ? box[a] : 0.0f; mx[a] = n ? box[3 + a] : 0.0f; }
     } else {
@@ -225,9 +228,12 @@ static int lio_map_finish(lio_s2m_handle* h, size_t n, std::chrono::steady_clock
         unsigned hb[6];
         HIPCHK(hipMemcpyAsync(hb, h->d_bbox, sizeof(hb), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        const bool empty = (n == 0) || hb[0] == 0xffffffffu;
+        bool empty = (n == 0) || hb[0] == 0xffffffffu;
+        // (a map without a single finite point leaves the reduction at its identities, max < min: an empty grid, every point outside it)
+        for (int a = 0; a < 3 && !empty; ++a) empty = !(lio_ord2f(hb[a]) <= lio_ord2f(hb[3 + a]));
         for (int a = 0; a < 3; ++a) { mn[a] = empty ? 0.0f : lio_ord2f(hb[a]); mx[a] = empty ? 0.0f : lio_ord2f(hb[3 + a]); }
     }
+
     auto t1 = std::chrono::steady_clock::now();
 
     // cell edge = gate radius (+0.1 %) / k; the candidate scan visits (2k+1)^3 cells

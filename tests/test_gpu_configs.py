@@ -89,8 +89,9 @@ def test_headline_512_scans_64x1800_vs_200_keyframes(pkg, oracle, synth):
     scans = [q["scan"] for q in case["queries"]]
     poses0 = np.stack([q["pose_init"] for q in case["queries"]])
     assert len(case["map"]) > 50000 and np.mean([len(s) for s in scans]) > 5000
-    g = pkg.ScanToMap(use_graph=1, graph_iters=12)
+    g = pkg.ScanToMap(use_graph=1, graph_iters=12, max_batch=512)             # the bench's handle: finer x buckets + a tight row table
     g.set_map(case["map"])
+    assert g.profile().map_x_sub == 4 and g.profile().map_tight_tables >= 1
     g.batch_upload(scans); g.batch_set_poses(poses0); g.batch_run()
     poses, res = g.batch_results()
     assert all(r.status == 0 and r.converged == 1 for r in res)

@@ -126,15 +126,24 @@ def test_too_few_points_and_too_few_corr(pkg, oracle, small_case):
     s2m.close()
 
 
-def test_empty_and_tiny_maps(pkg, oracle, small_case):
+@pytest.mark.parametrize("cfg", [dict(), dict(max_batch=64), dict(tight_rows=3, x_sub=8)])
+def test_empty_and_tiny_maps(pkg, oracle, small_case, cfg):
     q = small_case["queries"][0]
-    s2m = pkg.ScanToMap()
+    s2m = pkg.ScanToMap(**cfg)
     s2m.set_map(np.zeros((0, 3), np.float32))
     pose, res, rc = s2m.scan2MapOptimization(q["scan"], q["pose_init"])
     assert rc == 2 and np.array_equal(pose, q["pose_init"])
     s2m.set_map(small_case["map"][:3])            # fewer than 5 map points
     pose, res, rc = s2m.scan2MapOptimization(q["scan"], q["pose_init"])
     assert rc == 2 and np.array_equal(pose, q["pose_init"])
+    bad = np.full((40, 3), np.nan, np.float32)    # nothing but non-finite points: an empty grid
+    s2m.set_map(bad)
+    pose, res, rc = s2m.scan2MapOptimization(q["scan"], q["pose_init"])
+    assert rc == 2 and np.array_equal(pose, q["pose_init"])
+    s2m.set_map(small_case["map"])                # and the handle is as good as new afterwards
+    pose, res, rc = s2m.scan2MapOptimization(q["scan"], q["pose_init"])
+    pose_o, res_o, _, _ = oracle.scan2map(oracle.default_config(knn_mode=1, n_threads=8), q["scan"], small_case["map"], q["pose_init"])
+    assert rc == 0 and res.iters == res_o.iters and np.abs(pose - pose_o).max() <= 1e-5
     s2m.close()
 
 
@@ -142,7 +151,7 @@ def test_batch_matches_single(pkg, oracle, small_case):
     qs = small_case["queries"]
     scans = [q["scan"] for q in qs] + [qs[0]["scan"][:20]]   # ragged batch incl. a too-small scan
     poses0 = np.stack([q["pose_init"] for q in qs] + [qs[0]["pose_init"]])
-    s2m = pkg.ScanToMap()
+    s2m = pkg.ScanToMap(max_batch=64)
     s2m.set_map(small_case["map"])
     s2m.batch_upload(scans)
     s2m.batch_set_poses(poses0)
