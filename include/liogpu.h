@@ -463,12 +463,18 @@ int  lio_kf_store_create(int32_t device_id, lio_kf_store **out);
 void lio_kf_store_destroy(lio_kf_store *s);
 int  lio_kf_store_add(lio_kf_store *s, const void *cloud, size_t n, size_t stride_bytes, int32_t *id_out);
 int  lio_kf_store_count(const lio_kf_store *s);
+/* Points of keyframe `id` (0 for an id the store does not hold): what a caller adds up to size `out` of
+ * lio_assemble_map_resident. */
+size_t lio_kf_store_points(const lio_kf_store *s, int32_t id);
 /* The same from DEVICE memory (x,y,z @0,4,8, intensity @16 when stride >= 20, else 0): no host round trip. */
 int  lio_kf_store_add_device(lio_kf_store *s, const void *d_cloud, size_t n, size_t stride_bytes, int32_t *id_out);
 /* saveKeyFramesAndFactor MO:2136-2142 (`pcl::copyPointCloud(*laserCloudSurfLastDS, *thisSurfKeyFrame);
  * surfCloudKeyFrames.push_back(thisSurfKeyFrame)`): appends the scan that batch slot `scan` of `h` has just
  * registered (its records are still staged on the device) as a keyframe -- no D2H, no H2D. */
 int  lio_kf_store_add_from_handle(lio_kf_store *s, lio_s2m_handle *h, int32_t scan, int32_t *id_out);
+/* `out` (may be NULL) needs room for the SUM of the selected keyframes' points: the filter's output is at most that many,
+ * and exactly that many when the leaf overflows PCL's voxel index (or the clouds hold non-finite coordinates) and the
+ * input is passed through, as pcl::VoxelGrid does.  The same holds for `out` of lio_assemble_map (sum of n_pts). */
 int  lio_assemble_map_resident(lio_s2m_handle *h, lio_kf_store *s, int32_t n_selected, const int32_t *ids,
                                const float *poses, float leaf, void *out, size_t out_stride_bytes, size_t *n_out);
 

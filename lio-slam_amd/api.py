@@ -118,7 +118,7 @@ EXPORTS = [
     "lio_s2m_batch_iter_partial", "lio_s2m_batch_iter_apply", "lio_s2m_batch_n_active",
     "lio_transform_update", "lio_deskew_default_config", "lio_imu_deskew_info", "lio_deskew",
     "lio_curvature", "lio_s2m_debug_stamps", "lio_s2m_batch_poll_active", "lio_voxel_grid", "lio_assemble_map", "lio_kf_store_create", "lio_kf_store_destroy", "lio_kf_store_add",
-    "lio_kf_store_count", "lio_assemble_map_resident", "lio_s2m_set_scan_shard",
+    "lio_kf_store_count", "lio_kf_store_points", "lio_assemble_map_resident", "lio_s2m_set_scan_shard",
     "lio_s2m_set_corner_map", "lio_s2m_batch_upload_corners", "lio_s2m_register_cs",
     "lio_s2m_get_corner_correspondences", "lio_feature_default_config", "lio_extract_features",
     "lio_range_image_default_config", "lio_range_image",
@@ -212,6 +212,8 @@ def load_library():
     L.lio_kf_store_destroy.restype = None
     L.lio_kf_store_add.argtypes = [vp, vp, sz, sz, C.POINTER(i32)]
     L.lio_kf_store_count.argtypes = [vp]
+    L.lio_kf_store_points.argtypes = [vp, C.c_int32]
+    L.lio_kf_store_points.restype = C.c_size_t
     L.lio_kf_store_add_device.argtypes = [vp, vp, sz, sz, C.POINTER(i32)]
     L.lio_kf_store_add_from_handle.argtypes = [vp, vp, i32, C.POINTER(i32)]
     L.lio_assemble_map_resident.argtypes = [vp, vp, i32, C.POINTER(i32), C.POINTER(f32), f32, vp, sz, C.POINTER(sz)]
@@ -740,6 +742,8 @@ class KeyframeStore:
     def assemble(self, ids, poses, leaf, s2m=None, want_output=True, max_out=None):   # extractCloud, MO:1556-1588
         ids_a = np.ascontiguousarray(ids, np.int32)
         p = np.ascontiguousarray(poses, np.float32).reshape(len(ids_a), 6)
+        if want_output and max_out is None:          # room for every selected point: the filter may pass its input through
+            max_out = sum(int(self.lib.lio_kf_store_points(self.h, int(i))) for i in ids_a)
         out = np.zeros((max(max_out or 1, 1), 8), np.float32) if want_output else None
         n_out = C.c_size_t()
         rc = _check(self.lib.lio_assemble_map_resident(

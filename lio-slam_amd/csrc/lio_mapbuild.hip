@@ -306,7 +306,11 @@ int voxel_grid_device(const float4* d_in, int n, float leaf, B& out, int* n_out,
     const float inv = 1.0f / leaf;
     const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1,
                     dz = (long long)((mx[2] - mn[2]) * inv) + 1;
-    if (dx * dy * dz > 2147483647LL) {                       // "Leaf size is too small": PCL copies the input
+    // (a box that is not finite -- inf coordinates, or no finite point at all -- is outside what PCL defines: the conversions
+    // above are then meaningless; such a cloud takes the same way out as an overflowing index, deterministically)
+    bool finite_box = true;
+    for (int a = 0; a < 3; ++a) finite_box = finite_box && (mn[a] <= mx[a]) && fabsf(mn[a]) <= 3.0e38f && fabsf(mx[a]) <= 3.0e38f;
+    if (!finite_box || dx <= 0 || dy <= 0 || dz <= 0 || (double)dx * (double)dy * (double)dz > 2147483647.0) {   // "Leaf size is too small": PCL copies the input
         HIPCHK(out.alloc(sizeof(float4) * (size_t)n));
         HIPCHK(hipMemcpyAsync(out.p, d_in, sizeof(float4) * (size_t)n, hipMemcpyDeviceToDevice, s));
         *n_out = n;
@@ -419,6 +423,7 @@ extern "C" void lio_kf_store_destroy(lio_kf_store* s)
 }
 
 extern "C" int lio_kf_store_count(const lio_kf_store* s) { return s ? (int)s->off.size() : 0; }
+extern "C" size_t lio_kf_store_points(const lio_kf_store* s, int32_t id) { return (s && id >= 0 && (size_t)id < s->cnt.size()) ? s->cnt[(size_t)id] : 0; }
 
 static int kf_store_reserve(lio_kf_store* s, size_t n)
 {
