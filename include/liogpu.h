@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LIO_VERSION 101
+#define LIO_VERSION 102
 #define LIO_MAX_ITERS 32
 
 /* status codes */

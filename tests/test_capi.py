@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} is declared in include/liogpu.h but not exported"
-    assert lib.lio_version() == 101
+    assert lib.lio_version() == 102
 
 
 def test_struct_layouts_match_c(pkg):
