@@ -545,8 +545,9 @@ def main():
         issue = json.load(open(ipath))
         issue["source"] = ("stored figure: separate rocprofv3 --pmc passes of `bench.py --roofline-pass-only` by the builder (profiles/r03_pmc_SQ.txt, "
                            "r03_pmc_SQ2.txt, tools/issue_roofline.py), same workload as this run (scans_per_step, N_m checked); not a counter of this run")
-        issue["note"] = ("k_s2m_iterate issues a vector instruction in two of every three cycles of every SIMD while its divergent 16-byte candidate "
-                         "gathers keep the texture addresser busy 79 % of the time: it sits on both limiters, HBM is at 11 %")
+        issue["note"] = (f"k_s2m_iterate issues a vector instruction in {100 * issue['frac']:.0f} % of all cycles of every SIMD while its divergent "
+                         f"16-byte candidate gathers keep the texture addresser busy {100 * issue['texture_addresser_busy_frac']:.0f} % of the time: "
+                         "it sits on both limiters (and on the dependent loads five waves per SIMD only partly hide), HBM is at 12 %")
 
     out = {
         "metric": "scan-to-map registrations/sec, 64x1800 scan vs 200-keyframe map; pose RMSE",
@@ -583,9 +584,9 @@ def main():
                               "builder (profiles/r03_traffic.json, profiles/README.md), not a counter of this run",
             "kernel": "k_s2m_iterate",
             "ms_per_launch": ms_per_launch,
-            "limiter": "not HBM: VALU issue (about 2100 vector instructions per 64 live points and iteration, of which the candidate "
-                       "scan is ~40 % and the bit-exact plane fit ~40 %) with the divergent candidate gathers keeping the texture "
-                       "addresser ~79 % busy; see `roofline_issue` and DESIGN.md section 6",
+            "limiter": "not HBM: VALU issue (about 2100 vector instructions per 64 live points and iteration; the bit-exact plane fit is "
+                       "~40 % of them) with the divergent candidate gathers keeping the texture addresser ~78 % busy, over a chain of "
+                       "dependent loads per workgroup; see `roofline_issue` and DESIGN.md section 6",
             "launches_per_step": int(live.sum()), "launches_per_graph_replay": int(args.graph), "algorithmic_bytes_per_launch": bytes_per_launch,
             "launches_measured": int(roof["launches"]) if roof else int(live.sum()),
             "in_streamed_region": in_stream,
