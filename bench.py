@@ -6,9 +6,10 @@ resident in HBM.  One "step" = one batch of B scans taken through the WHOLE devi
 boundary: the raw pcl::PointXYZI records of the batch (resident in HBM when the timed region starts) are
 staged, tile-sorted into the SoA layout, every scan gets its own initial guess and runs the Gauss-Newton
 loop (<= 30 iterations, each scan stops at its own convergence, MO:1848-1859), and the B results are read
-back.  Every step registers a DIFFERENT batch (`--batches` distinct batches are cycled); two handles
-sharing the resident map form a double buffer: batch k+1 is staged, sorted and STARTED while batch k still
-iterates, and only then are the results of batch k collected.  The roofline of the dominant kernel is measured
+back.  Every step registers a DIFFERENT batch (`--batches` distinct batches are cycled); `--handles` (3)
+handles sharing the resident map form a software pipeline: batches k+1 and k+2 are staged, sorted and STARTED
+while batch k still iterates, and only then are the results of batch k collected (two handles leave the GPU
+alone with the tail of one batch while the host prepares the next: 357 k against 416 k registrations/s).  The roofline of the dominant kernel is measured
 in the same run by a separate pass in which the kernel has the GPU to itself (`--roofline-pass-only` makes
 that pass the only timed region, for rocprofv3).  Also reported, never as `value`: the same stream with the records coming from pinned HOST memory
 over PCIe (`streamed_h2d`), the GN loop alone on a pre-sorted resident batch (`gn_loop_only`, round 1's
@@ -196,6 +197,8 @@ def main():
     ap.add_argument("--roofline-pass-only", action="store_true", help="profiling: make the roofline pass (GN loop alone on one "
                     "pre-sorted resident batch, launches of k_s2m_iterate never overlapping anything) the ONLY timed region")
     ap.add_argument("--single-buffer", action="store_true", help="A/B: one handle, no overlap of staging and GN loop")
+    ap.add_argument("--handles", type=int, default=3, help="handles (batches in flight) of the streamed pipeline; measured on one MI355X: "
+                    "2 -> 357 k, 3 -> 416 k, 4 -> 375 k, 5 -> 382 k, 6 -> 357 k registrations/s")
     ap.add_argument("--maxsq", type=float, default=1.0, help="DIAGNOSTIC: squared 5-NN gate (reference: 1.0); smaller values shrink the "
                     "searched neighbourhood and change the results -- only for timing what-if runs")
     ap.add_argument("--lawnmower", action="store_true", help="keyframes on a lawn-mower path inside a 50 m radius (configs[3])")
@@ -387,9 +390,10 @@ def main():
         prof0 = hA.profile()
         handles = [hA]
         if not args.single_buffer and not inlib:
-            hB = pkg.ScanToMap(**kcfg)
-            hB.share_map(hA)
-            handles.append(hB)
+            for _ in range(max(1, int(os.environ.get("BENCH_HANDLES", args.handles)) - 1)):     # (BENCH_HANDLES: A/B runs)
+                hB = pkg.ScanToMap(**kcfg)
+                hB.share_map(hA)
+                handles.append(hB)
 
         def run_stream(n_steps, sources, first_batch=0, keep=None):
             """Software pipeline over the handles: while batch k iterates (asynchronous launch loop on its handle's stream),
@@ -406,15 +410,15 @@ def main():
                 h.batch_run()
 
             out = None
-            if nh > 1:
-                start(0)
+            for j in range(min(nh - 1, n_steps)):         # nh - 1 batches in flight ahead of the one being collected
+                start(j)
             for k in range(n_steps):
                 b = (first_batch + k) % NB
                 h = handles[k % nh]
                 if nh == 1:
                     start(k)
-                elif k + 1 < n_steps:
-                    start(k + 1)
+                elif k + nh - 1 < n_steps:
+                    start(k + nh - 1)
                 out = h.batch_results(with_results=False)[0]
                 if keep is not None:                      # launch accounting of EVERY timed step (HIP events on h's stream)
                     pr = h.profile()
@@ -564,7 +568,7 @@ def main():
             "timed_region": "ROOFLINE PASS ONLY (profiling run): GN loop of one pre-sorted resident batch" if (args.roofline_pass_only and not sharded) else
                             "per step, for a batch not seen in the previous step: staging of the raw records (resident in HBM) + AoS->SoA + "
                             "tile sort, B initial poses in, whole GN loop, B results out" + ("" if sharded else
-                            "; double-buffered over two handles sharing the map" if len(handles) > 1 else "; single handle"),
+                            f"; software-pipelined over {len(handles)} handles sharing the map ({len(handles) - 1} batches in flight ahead of the one being collected)" if len(handles) > 1 else "; single handle"),
             "inputs_resident_in_hbm": True, "h2d_in_timed_region": False, "input_record_bytes": stride,
             "scans_per_step": B, "distinct_batches": NB, "N_s_mean": float(n_s.mean()), "N_m": int(len(map_xyz)),
             "gn_iters_mean": float(iters.mean()), "gn_iters_max": int(iters.max()),
