@@ -633,6 +633,12 @@ extern "C" int lio_assemble_map(lio_s2m_handle* h, int32_t device_id, int32_t n_
 struct LioRawWs {
     LioKeep raw, xyzi, ds;
     LioVoxWs<LioKeep> vws;
+    // the upload and the voxel filter of the sweep run on a stream of their own: they do not depend on the local map, whose
+    // assembly (lio_assemble_map_resident: K6 + K7 + grid build, ~0.25 ms of small kernels) is usually still in flight on the
+    // handle's stream when the node calls lio_s2m_register_raw -- the two chains overlap on the GPU, and the filter's host
+    // waits (bounding box, voxel count) no longer wait for the map as well
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_in = nullptr, ev_done = nullptr;
 };
 
 void lio_raw_ws_free(LioRawWs* w)
@@ -641,6 +647,9 @@ void lio_raw_ws_free(LioRawWs* w)
     LioKeep* keep[] = { &w->raw, &w->xyzi, &w->ds, &w->vws.bbox, &w->vws.large, &w->vws.pairs_a, &w->vws.pairs_b, &w->vws.hist,
                         &w->vws.blk_heads, &w->vws.seg_start, &w->vws.d_no, &w->vws.row_total };
     for (LioKeep* k : keep) k->release();
+    if (w->ev_in) (void)hipEventDestroy(w->ev_in);
+    if (w->ev_done) (void)hipEventDestroy(w->ev_done);
+    if (w->aux) (void)hipStreamDestroy(w->aux);
     delete w;
 }
 
@@ -665,7 +674,12 @@ extern "C" int lio_s2m_register_raw(lio_s2m_handle* h, const void* data, size_t 
     if (rc != LIO_OK) return rc;
     if (!h->raw_ws) h->raw_ws = new LioRawWs();
     LioRawWs* w = h->raw_ws;
-    hipStream_t s = h->stream;
+    if (!w->aux) {
+        HIPCHK(hipStreamCreateWithFlags(&w->aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&w->ev_done, hipEventDisableTiming));
+    }
+    hipStream_t s = w->aux;                              // upload + filter here; the registration on h->stream, behind the map
     const size_t step = layout->point_step, n = n_points;
     // the blob: read in place when it is device memory of this device, else one H2D copy (a true DMA when pinned)
     const unsigned char* d_rec = nullptr;
@@ -680,6 +694,9 @@ extern "C" int lio_s2m_register_raw(lio_s2m_handle* h, const void* data, size_t 
         (void)hipGetLastError();                         // (pageable host memory is reported as an error)
         if (in_place) {
             d_rec = (const unsigned char*)data;
+            // (device memory may have been produced by work queued on the handle's stream: keep that order)
+            HIPCHK(hipEventRecord(w->ev_in, h->stream));
+            HIPCHK(hipStreamWaitEvent(s, w->ev_in, 0));
         } else {
             if (layout->pin_host) {
                 if (hipHostRegister(const_cast<void*>(data), n * step, hipHostRegisterDefault) == hipSuccess) pin.p = const_cast<void*>(data);
@@ -698,11 +715,14 @@ extern "C" int lio_s2m_register_raw(lio_s2m_handle* h, const void* data, size_t 
     rc = voxel_grid_device<LioKeep>(w->xyzi.as<float4>(), (int)n, leaf, w->ds, &no, s, w->vws, false, nullptr);
     if (rc < 0) return rc;                               // (rc == 1: PCL would pass the cloud through -- and so did we)
     if (n == 0) HIPCHK(w->ds.alloc(sizeof(float4)));
+    // the filter's last kernels (centroids) may still be in flight: the registration on the handle's stream waits for them
+    HIPCHK(hipEventRecord(w->ev_done, s));
+    HIPCHK(hipStreamWaitEvent(h->stream, w->ev_done, 0));
     h->int_off = 12;                                     // the staged records are float4 (x, y, z, intensity)
     const int rr = lio_s2m_register(h, w->ds.p, (size_t)no, sizeof(float4), pose, res);
     h->int_off = -2;
     if (rr < 0) return rr;
-    if (ds_out) { const int rc2 = copy_out(w->ds.as<float4>(), no, ds_out, ds_out_stride, s); if (rc2 < 0) return rc2; }
+    if (ds_out) { const int rc2 = copy_out(w->ds.as<float4>(), no, ds_out, ds_out_stride, h->stream); if (rc2 < 0) return rc2; }
     if (n_ds) *n_ds = (size_t)no;
     return rr;
 }
