@@ -166,8 +166,8 @@ __device__ static int feat_greedy_pass(const u64* s_sort, unsigned char* s_picke
         const bool valid = q <= m;
         int ind = ep;
         if (valid) {
-            if (CORNER) { if (q > 0) ind = (int)(unsigned)(s_sort[m - q] & 0xffffffffu); }
-            else        { if (q < m) ind = (int)(unsigned)(s_sort[q] & 0xffffffffu); }
+            if (CORNER) { if (q > 0) ind = w0 + (int)(unsigned)(s_sort[m - q] & 0x1fffu); }     // (keys carry the window-relative position)
+            else        { if (q < m) ind = w0 + (int)(unsigned)(s_sort[q] & 0x1fffu); }
         }
         const float cv = s_curv[ind - w0];
         const bool cand = valid && (CORNER ? cv > thr : cv < thr);
@@ -195,9 +195,9 @@ __device__ static int feat_greedy_pass(const u64* s_sort, unsigned char* s_picke
 
 __global__ __launch_bounds__(FEAT_BLOCK) void k_feat_ring(FeatParams P)
 {
-    // 32 KiB pool: greedy phase = curvature (16 K) + sector sort keys (8 K) + columns (8 K);
+    // 56 KiB pool: greedy phase = curvature (16 K) + sort keys of all six sectors (32 K) + columns (8 K);
     //              voxel phase  = (voxel index, list position) sort keys (32 K)
-    __shared__ __attribute__((aligned(16))) u64 s_pool[FEAT_MAX_RING];
+    __shared__ __attribute__((aligned(16))) u64 s_pool[FEAT_MAX_RING / 2 + FEAT_MAX_RING + FEAT_MAX_RING / 4];
     __shared__ unsigned char s_picked[FEAT_MAX_RING];
     __shared__ signed char s_label[FEAT_MAX_RING];
     __shared__ unsigned short s_list[FEAT_MAX_RING];        // surface candidates (window-relative), FE:224-229
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(FEAT_BLOCK) void k_feat_ring(FeatParams P)
     __shared__ int s_n_corner, s_n_list;
     __shared__ float s_box[6];
     float* s_curv = reinterpret_cast<float*>(s_pool);                       // [4096]
-    u64* s_sort = s_pool + FEAT_MAX_RING / 2;                               // [1024]
-    short* s_col = reinterpret_cast<short*>(s_pool + FEAT_MAX_RING / 2 + FEAT_MAX_SECT);   // [4096]
+    u64* s_sort = s_pool + FEAT_MAX_RING / 2;                               // [4096]
+    short* s_col = reinterpret_cast<short*>(s_pool + FEAT_MAX_RING / 2 + FEAT_MAX_RING);   // [4096]
 
     const int ring = blockIdx.x;
     const int start = P.start_ring[ring], end = P.end_ring[ring];
@@ -225,24 +225,47 @@ __global__ __launch_bounds__(FEAT_BLOCK) void k_feat_ring(FeatParams P)
     if (threadIdx.x == 0) { s_n_corner = 0; s_n_list = 0; }
     __syncthreads();
 
-    int first_valid = -1, last_valid = -1;                   // union of the sectors that were processed
+    // The six std::sort calls FE:162 as ONE sort: key = (sector, curvature, position) -- the sectors are disjoint ranges, so the
+    // sorted array is the six sorted sectors back to back (66 compare-exchange stages for 2048 keys instead of 6 x 45 for
+    // 6 x 512); ties inside a sector by position, as before.
+    int sec_sp[6], sec_ep[6], sec_off[7];
+    int n_keys = 0;
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
-        const int sp = (start * (6 - j) + end * j) / 6;                     // FE:156
-        const int ep = (start * (5 - j) + end * (j + 1)) / 6 - 1;           // FE:157
-        if (sp >= ep) continue;                                             // FE:159 (workgroup-uniform)
-        const int m = ep - sp;                                              // std::sort range [sp, ep), FE:162
-        if (m > FEAT_MAX_SECT) { if (threadIdx.x == 0) atomicExch(P.status, 2); return; }
-        const int mp = feat_pow2_at_least(m);
-        for (int t = threadIdx.x; t < mp; t += FEAT_BLOCK)
-            s_sort[t] = t < m ? (((u64)__float_as_uint(s_curv[sp + t - w0])) << 32) | (unsigned)(sp + t) : ~0ull;
+        sec_sp[j] = (start * (6 - j) + end * j) / 6;                        // FE:156
+        sec_ep[j] = (start * (5 - j) + end * (j + 1)) / 6 - 1;              // FE:157
+        sec_off[j] = n_keys;
+        if (sec_sp[j] < sec_ep[j]) n_keys += sec_ep[j] - sec_sp[j];         // std::sort range [sp, ep), FE:162
+    }
+    sec_off[6] = n_keys;
+    if (n_keys > 0) {
+        const int mp = feat_pow2_at_least(n_keys);
+        for (int t = threadIdx.x; t < mp; t += FEAT_BLOCK) {
+            u64 key = ~0ull;
+            if (t < n_keys) {
+                int j = 0;
+#pragma unroll
+                for (int q = 1; q < 6; ++q) if (t >= sec_off[q]) j = q;     // (an empty sector shares its offset with the next one: the last match wins)
+                const int pos = sec_sp[j] + (t - sec_off[j]);
+                key = ((u64)j << 45) | ((u64)(__float_as_uint(s_curv[pos - w0]) & 0x7fffffffu) << 13) | (u64)(pos - w0);
+            }
+            s_sort[t] = key;
+        }
         __syncthreads();
         feat_bitonic_sort(s_sort, mp);
+    }
+
+    int first_valid = -1, last_valid = -1;                   // union of the sectors that were processed
+    for (int j = 0; j < 6; ++j) {
+        const int sp = sec_sp[j], ep = sec_ep[j];
+        if (sp >= ep) continue;                                             // FE:159 (workgroup-uniform)
+        const u64* s_sec = s_sort + sec_off[j];                             // this sector's keys, ascending curvature
         if (threadIdx.x < 64) {                                             // wave 0; LDS ops of one wave retire in order
             int n_corner = s_n_corner;
-            n_corner = feat_greedy_pass<true>(s_sort, s_picked, s_label, s_curv, s_col, sp, ep, w0, P.n, P.edge_thr,
+            n_corner = feat_greedy_pass<true>(s_sec, s_picked, s_label, s_curv, s_col, sp, ep, w0, P.n, P.edge_thr,
                                               P.corner_idx + ring * FEAT_MAX_PICK, n_corner);     // FE:165-195
             if (threadIdx.x == 0) s_n_corner = n_corner;
-            feat_greedy_pass<false>(s_sort, s_picked, s_label, s_curv, s_col, sp, ep, w0, P.n, P.surf_thr,
+            feat_greedy_pass<false>(s_sec, s_picked, s_label, s_curv, s_col, sp, ep, w0, P.n, P.surf_thr,
                                     nullptr, 0);                                                   // FE:197-222
         }
         __syncthreads();
