@@ -196,8 +196,11 @@ int  lio_s2m_batch_results(lio_s2m_handle *h, float *poses /* n_scans x 6 */,
 /* ---- streaming: upload batch k+1 while batch k iterates (SURVEY 8d puts the per-scan H2D inside the metric;
  * the reference analogue is one cloud_info message arriving per callback, MO:432-476).
  * lio_s2m_share_map: handle `h` searches `map_owner`'s resident map (no copy); it keeps its own HIP stream,
- * scan buffers and per-scan state, so two handles form a double buffer:
+ * scan buffers and per-scan state, so several handles form a software pipeline -- two a double buffer:
  *     run(A) ... upload_async(B, next batch) ... results(A) ... run(B) ... upload_async(A, ...) ...
+ * THREE (two batches in flight ahead of the one whose results are awaited) measured 16 % faster than two: the host's
+ * preparation of the next upload then never leaves the GPU alone with the last, nearly empty launches of a batch
+ * (more than three streams oversubscribe the runtime's four hardware queues).
  * upload_async returns once the scans' H2D copies are DONE on h's stream (the caller's buffers are free
  * again) while the tile sort is still in flight; set_poses/run/results queue behind it.  Copies are true DMA
  * only from pinned memory: lio_host_alloc / lio_host_register (hipHostMalloc / hipHostRegister).  A batch laid
