@@ -307,7 +307,7 @@ LIO_DEV int lio_tile_coord(float v, float origin, float inv_tile, int n)
 }
 
 // ---- the whole upload-time reorder of ONE scan by ONE workgroup, in LDS ------------------------------------------
-// For scans of at most 16384 points (every downsampled scan; raw sweeps take the multi-kernel path below): bounding box
+// For scans of at most 16383 points (every downsampled scan; raw sweeps take the multi-kernel path below): bounding box
 // (finite coordinates), tile grid (the same arithmetic as the host code of the multi-kernel path: tile edge doubled
 // until the grid has <= 262144 tiles), key = (linear tile id << 14) | caller index, a stable sort of the 32-bit keys by tile
 // id, then perm[] and the SoA are written in sorted order.  Same permutation as the counting sort + rank sort (tile id
@@ -1334,7 +1334,7 @@ void lio_launch_scan_sort_lds(const void* stage, size_t stride, const LioScanSta
     if (max_pts <= 16 * LIO_SORT_THREADS)
         hipLaunchKernelGGL(k_scan_sort_radix<16>, dim3(n_scans), dim3(LIO_SORT_THREADS), 0, s,
                            (const unsigned char*)stage, stride, st, tile0, shard_axis, perm, x, y, z);
-    else                                                    // (the caller sends scans of at most 16384 points this way)
+    else                                                    // (the caller sends scans of at most 16383 points this way)
         hipLaunchKernelGGL(k_scan_sort_radix<32>, dim3(n_scans), dim3(LIO_SORT_THREADS), 0, s,
                            (const unsigned char*)stage, stride, st, tile0, shard_axis, perm, x, y, z);
 }

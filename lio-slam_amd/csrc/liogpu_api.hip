@@ -755,7 +755,9 @@ extern "C" int lio_s2m_batch_upload(lio_s2m_handle* h, int32_t n_scans, const vo
     h->sorted = false;
     // the tile sort pays for itself on batches; a lone small scan skips its eight launches
     const bool want_sort = total && (h->cfg.sort_scan >= 2 || (h->cfg.sort_scan == 1 && total >= 65536));
-    if (want_sort && max_n <= 16384 && h->cfg.sort_scan != 3) {
+    // (up to 16383 points: the key (tile id << 14) | index of a 16384th point in tile 262143 would be the 0xffffffff that marks
+    // an empty slot of k_scan_sort_radix)
+    if (want_sort && max_n < 16384 && h->cfg.sort_scan != 3) {
         // every scan fits one workgroup's LDS: bounding box, tile keys, sort and gather in ONE launch, nothing read back
         HIPCHK(lio_grow(&h->d_perm, &h->cap_perm, tt));
         lio_launch_scan_sort_lds(stage, stride, h->d_state, n_scans, (int)max_n, h->cfg.tile_size > 0.0f ? h->cfg.tile_size : 4.0f,

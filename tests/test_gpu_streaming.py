@@ -167,7 +167,7 @@ def test_one_launch_lds_sort_equals_the_counting_sort(pkg, small_case):
 
 def test_lds_sort_size_boundaries(pkg, small_case):
     """The one-launch sort (one workgroup per scan: radix sort with the keys in registers, 16 rows of 64 per wave up to 8192
-    points, 32 rows up to 16384) takes scans of up to 16384 points; one point more and the batch goes through the multi-kernel
+    points, 32 rows above) takes scans of up to 16383 points; one point more and the batch goes through the multi-kernel
     counting sort.  Same results on both sides of every boundary."""
     rng = np.random.default_rng(9)
     m = small_case["map"]
